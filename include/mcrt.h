@@ -1,0 +1,262 @@
+/*
+ * mcrt.h - C ABI of the MI355X path-tracing backend (libmcrt_hip.so).
+ *
+ * This is the drop-in boundary for the reference renderer's CPU per-pixel
+ * render loop.  The reference (DennyLindberg/Monte-Carlo-Ray-Tracer) has no
+ * FFI of its own; the calls below replace, one for one, what its worker
+ * threads do through the public C++ class API.  Every entry point cites the
+ * reference interface it stands in for as `source/<file>:<line>` (paths
+ * relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no C++ or torch types cross it;
+ *   - every function returns an int status (MCRT_OK == 0) and never throws;
+ *   - the library never takes ownership of caller memory;
+ *   - one mcrt_ctx is used from one host thread at a time; multi-GPU means
+ *     one context (and normally one process) per device;
+ *   - there is NO CPU fallback: without a HIP device mcrt_create fails.
+ */
+#ifndef MCRT_H
+#define MCRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- status */
+#define MCRT_OK 0
+#define MCRT_ERR_INVALID 1     /* bad argument / bad scene description      */
+#define MCRT_ERR_NO_DEVICE 2   /* no HIP device, or device_id out of range  */
+#define MCRT_ERR_HIP 3         /* a HIP runtime call failed                 */
+#define MCRT_ERR_STATE 4       /* call order violated (no scene/camera yet) */
+#define MCRT_ERR_LIMIT 5       /* a documented size limit was exceeded      */
+
+/* ------------------------------------------------------- scene description
+ * POD mirror of the reference's scene graph after
+ * Scene::PrepareForRayTracing (source/scene.cpp:38-59).  Objects keep their
+ * insertion order because that order is the nearest-hit tie-break order
+ * (source/scene.cpp:71-76). */
+
+/* SurfaceType / DiffuseType, source/core/material.h:8-9 */
+enum { MCRT_SURFACE_DIFFUSE = 0, MCRT_SURFACE_SPECULAR = 1,
+       MCRT_SURFACE_DIFFUSE_SPECULAR = 2, MCRT_SURFACE_REFRACTIVE = 3 };
+enum { MCRT_DIFFUSE_LAMBERTIAN = 0, MCRT_DIFFUSE_OREN_NAYAR = 1 };
+
+/* struct Material, source/core/material.h:11-19 */
+typedef struct mcrt_material {
+    double color[3];
+    double emission[3];
+    int32_t surface;           /* MCRT_SURFACE_*  */
+    int32_t diffuse;           /* MCRT_DIFFUSE_*  */
+    float albedo;
+    float roughness;
+    float refractive_index;
+    int32_t reserved;
+} mcrt_material;
+
+/* struct Triangle, source/core/triangle.h:8-23 (three vertices + the face
+ * normal its constructor derives). */
+typedef struct mcrt_triangle {
+    float v0[3];
+    float v1[3];
+    float v2[3];
+    float normal[3];
+} mcrt_triangle;
+
+/* Which concrete reference class an object is. */
+enum {
+    MCRT_OBJECT_SPHERE = 0,    /* SphereObject, source/objects/sphere.h:8   */
+    MCRT_OBJECT_MESH = 1,      /* TriangleMesh / Box, source/objects/mesh.h */
+    MCRT_OBJECT_LIGHT = 2      /* Light (quad emitter), objects/light.h:8   */
+};
+
+/* class Object and its subclasses, source/objects/object.h:12-33. */
+typedef struct mcrt_object {
+    int32_t kind;              /* MCRT_OBJECT_*                             */
+    uint32_t first_triangle;   /* into mcrt_scene_desc.triangles (meshes)   */
+    uint32_t triangle_count;
+    float radius;              /* SphereObject::radius                      */
+    float position[3];         /* Object::position                          */
+    float aabb_min[3];         /* Object::aabb after UpdateAABB (meshes):   */
+    float aabb_max[3];         /*   the per-mesh gate of objects/mesh.cpp:11 */
+    float light_x[3];          /* Light::xVector (half extent)              */
+    float light_y[3];          /* Light::yVector (half extent)              */
+    mcrt_material material;
+} mcrt_object;
+
+typedef struct mcrt_scene_desc {
+    uint32_t object_count;
+    uint32_t triangle_count;
+    const mcrt_object* objects;
+    const mcrt_triangle* triangles;
+    double background[3];      /* Scene::backgroundColor, source/scene.h:26 */
+} mcrt_scene_desc;
+
+/* class Camera, source/core/camera.h:9-58, after SetView. */
+typedef struct mcrt_camera {
+    float position[3];
+    float fov_scale;           /* Camera::fovPixelScale                     */
+    float view[16];            /* inverse(lookAtRH), column-major like glm  */
+    uint32_t width;
+    uint32_t height;
+} mcrt_camera;
+
+/* How nearest-hit queries walk the scene. Results are identical by
+ * construction; BRUTE restates source/scene.cpp:62-80 literally and is the
+ * on-device cross-check for the octree. */
+enum { MCRT_ACCEL_OCTREE = 0, MCRT_ACCEL_BRUTE = 1 };
+
+typedef struct mcrt_accel_params {
+    uint32_t max_leaf_prims;   /* Octree::maxCount analogue (octree.h:31); 0 = default */
+    uint32_t max_depth;        /* 0 = default                               */
+    float pad_rel;             /* node box padding, fraction of root extent; 0 = default */
+} mcrt_accel_params;
+
+/* Tonemap switch of source/main.cpp:45-48,144-164. */
+enum { MCRT_TONEMAP_NONE = 0, MCRT_TONEMAP_REINHARD = 1, MCRT_TONEMAP_EXPOSURE = 2 };
+
+typedef struct mcrt_ctx mcrt_ctx;
+
+/* ------------------------------------------------------------- life cycle */
+
+/* Bind a context to HIP device `device_id`.  Replaces the implicit "this
+ * process renders on the CPU" of source/main.cpp:220-262. */
+int mcrt_create(int device_id, mcrt_ctx** out_ctx);
+int mcrt_destroy(mcrt_ctx* ctx);
+
+/* Text of the last failure on this context (or of the last failed
+ * mcrt_create when ctx is NULL).  The reference reports failure as
+ * false/nullptr only (source/scene.cpp:79). */
+const char* mcrt_last_error(const mcrt_ctx* ctx);
+
+/* Launch all later work of this context on the caller's hipStream_t
+ * (NULL = the context's own stream).  No reference counterpart. */
+int mcrt_set_stream(mcrt_ctx* ctx, void* hip_stream);
+
+/* ------------------------------------------------------------ scene/camera */
+
+/* Flatten + upload the scene: Scene::PrepareForRayTracing,
+ * source/scene.cpp:38-59 (light cache :41-49; the octree of
+ * source/accelerationstructures/octree.h:77-92 is rebuilt here as a flat,
+ * per-primitive SoA structure).  `accel` may be NULL. */
+int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* scene,
+                      const mcrt_accel_params* accel);
+
+/* Camera::Camera + Camera::SetView, source/core/camera.h:19-34; also sizes
+ * the PixelBuffer accumulators (source/core/pixelbuffer.cpp:7-23). */
+int mcrt_set_camera(mcrt_ctx* ctx, const mcrt_camera* camera);
+
+/* Choose MCRT_ACCEL_OCTREE (default) or MCRT_ACCEL_BRUTE for later calls. */
+int mcrt_set_accel(mcrt_ctx* ctx, int accel_mode);
+
+/* ------------------------------------------------------------ parity paths */
+
+/* Camera::GetPixelRay(x, y), source/core/camera.h:36-57, for n pixel
+ * positions.  Host buffers; out arrays are n*3 floats. */
+int mcrt_camera_rays(mcrt_ctx* ctx, uint64_t n, const float* xs, const float* ys,
+                     float* out_origins, float* out_dirs);
+
+/* Scene::IntersectRay, source/scene.cpp:62-80, for n rays (host buffers,
+ * n*3 floats each).  out_obj = object index or -1 on a miss, out_elem =
+ * RayIntersectionInfo::elementIndex, out_t = hitDistance (FLT_MAX on a miss),
+ * source/core/ray.h:17-29. */
+int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const float* origins, const float* dirs,
+                   int32_t* out_obj, uint32_t* out_elem, float* out_t);
+
+/* Same, all five arrays already in device memory (no copies, no sync). */
+int mcrt_intersect_device(mcrt_ctx* ctx, uint64_t n, const float* d_origins,
+                          const float* d_dirs, int32_t* d_obj, uint32_t* d_elem,
+                          float* d_t);
+
+/* Per-sample radiance, i.e. one iteration of the spp loop of
+ * source/main.cpp:122-139 without the Accumulate: jitter, GetPixelRay,
+ * Scene::TraceRay (source/scene.cpp:94-234) with max_depth.  Sample k uses
+ * pixel index pixels[k] (= y*width + x) and sample index samples[k]; its
+ * random stream is mcrt_rng_seed(seed, pixel, sample).  out = n*3 doubles. */
+int mcrt_trace_samples(mcrt_ctx* ctx, uint64_t n, const uint32_t* pixels,
+                       const uint32_t* samples, uint64_t seed, uint32_t max_depth,
+                       double* out_radiance);
+
+/* Scene::TraceUnlit, source/scene.cpp:82-92, through pixel centres
+ * (source/main.cpp:126).  out = width*height*3 doubles. */
+int mcrt_render_unlit(mcrt_ctx* ctx, double* out_color);
+
+/* ----------------------------------------------------------------- render */
+
+/* Initial state of the xorshift128+ generator (source/core/randomization.h:
+ * 35-43) for one camera sample: the counter (seed, pixel, sample) hashed to
+ * 128 bits.  Pure host function; the kernels use the same mapping. */
+void mcrt_rng_seed(uint64_t seed, uint32_t pixel, uint32_t sample, uint64_t out_state[2]);
+
+/* Zero the radiance accumulators: PixelBuffer ctor loop,
+ * source/core/pixelbuffer.cpp:14-18. */
+int mcrt_clear(mcrt_ctx* ctx);
+
+/* Use caller-owned device memory (width*height*3 doubles) as the radiance
+ * accumulator, so the caller can all-reduce it (RCCL) between passes.
+ * NULL returns to the context's own buffer.  No reference counterpart. */
+int mcrt_bind_accumulator(mcrt_ctx* ctx, double* d_accum);
+
+/* Device address of the accumulator currently in use. */
+int mcrt_accumulator(mcrt_ctx* ctx, double** out_d_accum);
+
+/* The hot loop: TracePixels/RayTraceNextPixel, source/main.cpp:100-184, for
+ * every pixel and for samples [sample_begin, sample_begin+sample_count):
+ * PixelBuffer::Accumulate (source/core/pixelbuffer.cpp:39-46) into the device
+ * accumulators.  Asynchronous on the context's stream.  Non-finite samples
+ * are dropped (stated deviation). */
+int mcrt_render(mcrt_ctx* ctx, uint32_t sample_begin, uint32_t sample_count,
+                uint32_t max_depth, uint64_t seed);
+
+/* Milliseconds the last mcrt_render launch took on the device, from HIP
+ * events recorded on the context's stream around the kernel (synchronises). */
+int mcrt_last_render_ms(mcrt_ctx* ctx, float* out_ms);
+
+/* Mean, tonemap, gamma, clamp, x255 truncate, BGRA8: source/main.cpp:142-164
+ * and GLImageBuffer::SetPixel, source/opengl/data.cpp:28-55.  spp_total is
+ * the divisor (PixelBuffer::GetRayCount).  Either output may be NULL;
+ * out_bgra8 = width*height*4 bytes, out_mean = width*height*3 doubles (host). */
+int mcrt_resolve(mcrt_ctx* ctx, int tonemap, double gamma, double exposure,
+                 uint64_t spp_total, uint8_t* out_bgra8, double* out_mean);
+
+/* Copy the raw accumulator sums to the host (width*height*3 doubles). */
+int mcrt_read_accumulator(mcrt_ctx* ctx, double* out_sums);
+
+/* Block until everything queued on the context's stream has finished. */
+int mcrt_synchronize(mcrt_ctx* ctx);
+
+/* ------------------------------------------------------------ introspection */
+
+typedef struct mcrt_octree_info {
+    uint32_t node_count;
+    uint32_t prim_ref_count;   /* entries in the per-node primitive lists   */
+    uint32_t prim_count;       /* triangles + spheres                       */
+    uint32_t max_depth;
+    uint32_t blob_bytes;       /* size of the packed scene image            */
+    uint32_t lds_resident;     /* 1 when kernels stage the whole image in LDS */
+} mcrt_octree_info;
+
+int mcrt_octree_info_get(mcrt_ctx* ctx, mcrt_octree_info* out);
+
+/* Download the flat octree (test infrastructure reads it to replay the same
+ * traversal on the CPU with visit counters).  Arrays may be NULL to skip.
+ * node_box: node_count*6 floats (min xyz, max xyz); node_words:
+ * node_count*2 uint32 (child word, first primitive ref); prim_refs:
+ * prim_ref_count uint32. */
+int mcrt_octree_download(mcrt_ctx* ctx, float* node_box, uint32_t* node_words,
+                         uint32_t* prim_refs);
+
+/* Work counters of the last mcrt_render / mcrt_intersect when counting was
+ * enabled with mcrt_set_counting(ctx, 1): [0] rays, [1] nodes visited,
+ * [2] triangles tested, [3] spheres tested, [4] mesh gates evaluated,
+ * [5] camera samples, [6] TraceRay calls, [7] refractive splits. */
+int mcrt_set_counting(mcrt_ctx* ctx, int enabled);
+int mcrt_counters(mcrt_ctx* ctx, uint64_t out[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCRT_H */
