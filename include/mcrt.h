@@ -249,6 +249,18 @@ int mcrt_octree_info_get(mcrt_ctx* ctx, mcrt_octree_info* out);
 int mcrt_octree_download(mcrt_ctx* ctx, float* node_box, uint32_t* node_words,
                          uint32_t* prim_refs);
 
+/* Host-only: flatten a scene (validation, light cache, octree build, packing)
+ * without touching a GPU, for inspection and CPU-side tests.  mcrt_upload_scene
+ * runs exactly this and then copies the image to the device.  Errors are
+ * reported through mcrt_last_error(NULL). */
+typedef struct mcrt_scene_image mcrt_scene_image;
+int mcrt_scene_image_create(const mcrt_scene_desc* scene, const mcrt_accel_params* accel,
+                            mcrt_scene_image** out_image);
+int mcrt_scene_image_destroy(mcrt_scene_image* image);
+int mcrt_scene_image_info(const mcrt_scene_image* image, mcrt_octree_info* out);
+int mcrt_scene_image_octree(const mcrt_scene_image* image, float* node_box, uint32_t* node_words,
+                            uint32_t* prim_refs);
+
 /* Work counters of the last mcrt_render / mcrt_intersect when counting was
  * enabled with mcrt_set_counting(ctx, 1): [0] rays, [1] nodes visited,
  * [2] triangles tested, [3] spheres tested, [4] mesh gates evaluated,

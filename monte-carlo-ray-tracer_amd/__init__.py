@@ -1,0 +1,214 @@
+"""Python plumbing over the C ABI of libmcrt_hip.so (include/mcrt.h).
+
+The product is the HIP library; this module only loads it with ctypes, mirrors
+its entry points one to one and raises on every non-zero status.  There is no
+CPU fallback: if the library is missing or no HIP device is present, calls
+fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .abi import (  # noqa: F401
+    ACCEL_BRUTE, ACCEL_OCTREE, TONEMAP_EXPOSURE, TONEMAP_NONE, TONEMAP_REINHARD, AccelParams, Camera, FlatScene, OctreeInfo,
+)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmcrt_hip.so")
+
+# every symbol include/mcrt.h declares
+ABI_SYMBOLS = (
+    "mcrt_create", "mcrt_destroy", "mcrt_last_error", "mcrt_set_stream", "mcrt_upload_scene", "mcrt_set_camera", "mcrt_set_accel",
+    "mcrt_camera_rays", "mcrt_intersect", "mcrt_intersect_device", "mcrt_trace_samples", "mcrt_render_unlit", "mcrt_rng_seed",
+    "mcrt_clear", "mcrt_bind_accumulator", "mcrt_accumulator", "mcrt_render", "mcrt_last_render_ms", "mcrt_resolve",
+    "mcrt_read_accumulator", "mcrt_synchronize", "mcrt_octree_info_get", "mcrt_octree_download", "mcrt_set_counting", "mcrt_counters",
+    "mcrt_scene_image_create", "mcrt_scene_image_destroy", "mcrt_scene_image_info", "mcrt_scene_image_octree",
+)
+
+_lib = None
+
+
+class McrtError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"mcrt status {code}: {text}")
+        self.code = code
+
+
+def load_library(path=LIB_PATH):
+    """dlopen the HIP library (needs libamdhip64, not a GPU)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` or make -C {HERE}/csrc")
+        lib = C.CDLL(path)
+        lib.mcrt_last_error.restype = C.c_char_p
+        lib.mcrt_last_error.argtypes = [C.c_void_p]
+        lib.mcrt_rng_seed.restype = None
+        _lib = lib
+    return _lib
+
+
+def rng_seed(seed, pixel, sample):
+    out = (C.c_uint64 * 2)()
+    load_library().mcrt_rng_seed(C.c_uint64(seed), C.c_uint32(pixel), C.c_uint32(sample), out)
+    return int(out[0]), int(out[1])
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def build_scene_image(flat, accel=None):
+    """Host-only flatten (no GPU): returns (OctreeInfo, node_box, node_words, prim_refs)."""
+    lib = load_library()
+    img = C.c_void_p()
+    d = flat.desc()
+    rc = lib.mcrt_scene_image_create(C.byref(d), C.byref(accel) if accel is not None else None, C.byref(img))
+    if rc:
+        raise McrtError(rc, (lib.mcrt_last_error(None) or b"").decode())
+    try:
+        info = OctreeInfo()
+        lib.mcrt_scene_image_info(img, C.byref(info))
+        box = np.zeros((info.node_count, 6), np.float32)
+        words = np.zeros((info.node_count, 2), np.uint32)
+        refs = np.zeros(info.prim_ref_count, np.uint32)
+        lib.mcrt_scene_image_octree(img, _ptr(box, C.c_float), _ptr(words, C.c_uint32), _ptr(refs, C.c_uint32))
+    finally:
+        lib.mcrt_scene_image_destroy(img)
+    return info, box, words, refs
+
+
+COUNTER_NAMES = ("rays", "nodes", "tris", "spheres", "gates", "samples", "trace_calls", "splits")
+
+
+class Backend:
+    """One mcrt_ctx bound to one GPU."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.ctx = C.c_void_p()
+        rc = self.lib.mcrt_create(C.c_int(device), C.byref(self.ctx))
+        if rc:
+            raise McrtError(rc, (self.lib.mcrt_last_error(None) or b"").decode())
+        self.width = self.height = 0
+
+    def close(self):
+        if getattr(self, "ctx", None) and self.ctx.value:
+            self.lib.mcrt_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            raise McrtError(rc, (self.lib.mcrt_last_error(self.ctx) or b"").decode())
+
+    # ---------------------------------------------------------------- setup
+    def set_stream(self, stream_handle):
+        self._ck(self.lib.mcrt_set_stream(self.ctx, C.c_void_p(stream_handle)))
+
+    def upload_scene(self, flat, accel=None):
+        d = flat.desc()
+        self._ck(self.lib.mcrt_upload_scene(self.ctx, C.byref(d), C.byref(accel) if accel is not None else None))
+
+    def set_camera(self, cam):
+        self._ck(self.lib.mcrt_set_camera(self.ctx, C.byref(cam)))
+        self.width, self.height = int(cam.width), int(cam.height)
+
+    def set_accel(self, mode):
+        self._ck(self.lib.mcrt_set_accel(self.ctx, C.c_int(mode)))
+
+    def set_counting(self, on):
+        self._ck(self.lib.mcrt_set_counting(self.ctx, C.c_int(int(on))))
+
+    def counters(self):
+        out = (C.c_uint64 * 8)()
+        self._ck(self.lib.mcrt_counters(self.ctx, out))
+        return dict(zip(COUNTER_NAMES, (int(x) for x in out)))
+
+    def octree_info(self):
+        info = OctreeInfo()
+        self._ck(self.lib.mcrt_octree_info_get(self.ctx, C.byref(info)))
+        return info
+
+    def octree_download(self):
+        info = self.octree_info()
+        box = np.zeros((info.node_count, 6), np.float32)
+        words = np.zeros((info.node_count, 2), np.uint32)
+        refs = np.zeros(info.prim_ref_count, np.uint32)
+        self._ck(self.lib.mcrt_octree_download(self.ctx, _ptr(box, C.c_float), _ptr(words, C.c_uint32), _ptr(refs, C.c_uint32)))
+        return box, words, refs
+
+    # ---------------------------------------------------------- parity paths
+    def camera_rays(self, xs, ys):
+        xs, ys = _f32(xs), _f32(ys)
+        o = np.zeros((len(xs), 3), np.float32)
+        d = np.zeros((len(xs), 3), np.float32)
+        self._ck(self.lib.mcrt_camera_rays(self.ctx, C.c_uint64(len(xs)), _ptr(xs, C.c_float), _ptr(ys, C.c_float), _ptr(o, C.c_float), _ptr(d, C.c_float)))
+        return o, d
+
+    def intersect(self, origins, dirs):
+        o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)
+        n = len(o)
+        obj = np.zeros(n, np.int32); elem = np.zeros(n, np.uint32); t = np.zeros(n, np.float32)
+        self._ck(self.lib.mcrt_intersect(self.ctx, C.c_uint64(n), _ptr(o, C.c_float), _ptr(d, C.c_float), _ptr(obj, C.c_int32), _ptr(elem, C.c_uint32), _ptr(t, C.c_float)))
+        return obj, elem, t
+
+    def intersect_device(self, n, d_origins, d_dirs, d_obj, d_elem, d_t):
+        """All arguments are raw device addresses (ints)."""
+        self._ck(self.lib.mcrt_intersect_device(self.ctx, C.c_uint64(n), C.c_void_p(d_origins), C.c_void_p(d_dirs), C.c_void_p(d_obj), C.c_void_p(d_elem), C.c_void_p(d_t)))
+
+    def trace_samples(self, pixels, samples, seed, max_depth):
+        px = np.ascontiguousarray(pixels, np.uint32); sm = np.ascontiguousarray(samples, np.uint32)
+        out = np.zeros((len(px), 3), np.float64)
+        self._ck(self.lib.mcrt_trace_samples(self.ctx, C.c_uint64(len(px)), _ptr(px, C.c_uint32), _ptr(sm, C.c_uint32), C.c_uint64(seed), C.c_uint32(max_depth), _ptr(out, C.c_double)))
+        return out
+
+    def render_unlit(self):
+        out = np.zeros((self.height, self.width, 3), np.float64)
+        self._ck(self.lib.mcrt_render_unlit(self.ctx, _ptr(out, C.c_double)))
+        return out
+
+    # ----------------------------------------------------------------- render
+    def clear(self):
+        self._ck(self.lib.mcrt_clear(self.ctx))
+
+    def bind_accumulator(self, device_address):
+        self._ck(self.lib.mcrt_bind_accumulator(self.ctx, C.c_void_p(device_address)))
+
+    def accumulator_address(self):
+        p = C.c_void_p()
+        self._ck(self.lib.mcrt_accumulator(self.ctx, C.byref(p)))
+        return p.value
+
+    def render(self, sample_begin, sample_count, max_depth, seed):
+        self._ck(self.lib.mcrt_render(self.ctx, C.c_uint32(sample_begin), C.c_uint32(sample_count), C.c_uint32(max_depth), C.c_uint64(seed)))
+
+    def last_render_ms(self):
+        ms = C.c_float()
+        self._ck(self.lib.mcrt_last_render_ms(self.ctx, C.byref(ms)))
+        return float(ms.value)
+
+    def resolve(self, tonemap, spp_total, gamma=2.2, exposure=1.0, want_mean=True):
+        bgra = np.zeros((self.height, self.width, 4), np.uint8)
+        mean = np.zeros((self.height, self.width, 3), np.float64) if want_mean else None
+        self._ck(self.lib.mcrt_resolve(self.ctx, C.c_int(tonemap), C.c_double(gamma), C.c_double(exposure), C.c_uint64(spp_total), _ptr(bgra, C.c_uint8), _ptr(mean, C.c_double) if want_mean else None))
+        return bgra, mean
+
+    def read_accumulator(self):
+        out = np.zeros((self.height, self.width, 3), np.float64)
+        self._ck(self.lib.mcrt_read_accumulator(self.ctx, _ptr(out, C.c_double)))
+        return out
+
+    def synchronize(self):
+        self._ck(self.lib.mcrt_synchronize(self.ctx))

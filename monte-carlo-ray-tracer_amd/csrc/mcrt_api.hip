@@ -1,0 +1,1032 @@
+// mcrt_api.hip - kernels and the C ABI of libmcrt_hip.so (include/mcrt.h).
+//
+// Kernel family (all hand-written for gfx950, 64-wide wavefronts):
+//   k_render        the hot loop of source/main.cpp:100-184 + Scene::TraceRay
+//                   (source/scene.cpp:94-234): persistent workgroups pull 8x8
+//                   pixel tiles from an atomic counter; one lane owns one pixel
+//                   and walks its samples; every loop iteration is exactly one
+//                   nearest-hit query (camera/bounce ray or shadow ray), so the
+//                   wave stays converged on the expensive part while lanes sit in
+//                   different path states.
+//   k_trace_list    the same per-sample code on an explicit (pixel, sample) list
+//                   (parity entry point mcrt_trace_samples).
+//   k_intersect     Scene::IntersectRay (source/scene.cpp:62-80) on a ray batch.
+//   k_camera_rays   Camera::GetPixelRay (source/core/camera.h:36-57).
+//   k_unlit         Scene::TraceUnlit (source/scene.cpp:82-92).
+//   k_resolve       mean / tonemap / gamma / BGRA8 (source/main.cpp:142-164,
+//                   source/opengl/data.cpp:28-55).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "mcrt.h"
+#include "mcrt_device.h"
+#include "mcrt_flatten.h"
+
+using namespace mcrt;
+
+namespace {
+
+constexpr int kBlock = 256;                 // 4 wavefronts
+constexpr uint32_t kPendFields = 14;        // words per parked reflect branch: o(3) d(3) importance(6) depth(1) pad(1)
+constexpr uint32_t kMaxDepthLimit = 256;    // bound on max_depth (size of the parked-branch stack)
+constexpr uint32_t kLdsBudgetBytes = 96 * 1024;  // whole-scene LDS residency threshold
+
+// ------------------------------------------------------------------ staging
+// Copy the scene image(s) into LDS.  Returns the LDS view of SMALL; BIG follows it when resident.
+template <bool kBigLds>
+__device__ __forceinline__ void stage_scene(const SceneView& v, uint32_t* smem)
+{
+    for (uint32_t i = threadIdx.x; i < v.small_words; i += blockDim.x) smem[i] = v.small_img[i];
+    if (kBigLds) {
+        uint32_t base = (v.small_words + 3u) & ~3u;
+        for (uint32_t i = threadIdx.x; i < v.big_words; i += blockDim.x) smem[base + i] = v.big_img[i];
+    }
+    __syncthreads();
+}
+
+template <bool kBigLds> struct BigPtr;
+template <> struct BigPtr<true> { typedef LdsPtr type; };
+template <> struct BigPtr<false> { typedef GlbPtr type; };
+
+template <bool kBigLds>
+__device__ __forceinline__ typename BigPtr<kBigLds>::type big_ptr(const SceneView& v, uint32_t* smem);
+template <> __device__ __forceinline__ LdsPtr big_ptr<true>(const SceneView& v, uint32_t* smem)
+{
+    return (LdsPtr)(smem + ((v.small_words + 3u) & ~3u));
+}
+template <> __device__ __forceinline__ GlbPtr big_ptr<false>(const SceneView& v, uint32_t*) { return v.big_img; }
+
+// ------------------------------------------------------------ parked branches
+// Reflect branches of refractive splits (source/scene.cpp:212-213) wait here while the refract
+// branch runs.  One column per launched lane; fields interleaved so a wave touches consecutive words.
+struct PendStack {
+    uint32_t* base;
+    uint32_t lanes;    // total launched lanes
+    uint32_t lane;     // this lane's column
+    __device__ __forceinline__ uint32_t* at(uint32_t entry, uint32_t field) const
+    {
+        return base + ((size_t)entry * kPendFields + field) * lanes + lane;
+    }
+};
+
+struct RenderCounters { uint32_t samples, trace_calls, splits; };
+
+enum : uint32_t { ST_NEW = 0, ST_TRACE = 1, ST_SHADOW = 2, ST_DONE = 3 };
+
+// One lane: samples [s_begin, s_begin + s_count) of `pixel`.  Returns the sum of the finite
+// samples in sample order (keep_nonfinite: return the raw value, used by the parity path with
+// s_count == 1) and the number dropped.
+template <class PS, class PB, int kAccel, bool kCount>
+__device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, const CameraDev& cam, uint32_t pixel, uint32_t s_begin,
+                                           uint32_t s_count, uint64_t seed, uint32_t max_depth, const PendStack& pend,
+                                           bool keep_nonfinite, D3& sum, uint32_t& dropped, Counters& cn, RenderCounters& rc)
+{
+    sum = dmk(0.0, 0.0, 0.0);
+    dropped = 0;
+    const uint32_t px = pixel % cam.width, py = pixel / cam.width;
+    const D3 background = ldd3(sm, v.off_bg);
+
+    uint32_t state = s_count ? ST_NEW : ST_DONE;
+    uint32_t k = 0;
+    Rng g; g.s0 = 0; g.s1 = 0;
+    V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);       // ray of the current query
+    D3 imp = dmk(1, 1, 1), L = dmk(0, 0, 0);
+    uint32_t depth = 0, npend = 0;
+    // diffuse-hit context kept across the shadow queries
+    V3 hp = mk(0, 0, 0), hn = mk(0, 0, 0), hd = mk(0, 0, 0);
+    D3 direct = dmk(0, 0, 0);
+    uint32_t horec = 0, light_i = 0;
+
+    while (state != ST_DONE) {
+        if (state == ST_NEW) {
+            // one iteration of the spp loop, source/main.cpp:122-139
+            uint64_t a, b;
+            sample_seed(seed, pixel, s_begin + k, a, b);
+            g.s0 = a; g.s1 = b;
+            float sx = rng_float(g);
+            float sy = rng_float(g);
+            camera_ray(cam, (float)px + sx, (float)py + sy, ro, rd);
+            imp = dmk(1.0, 1.0, 1.0);
+            L = dmk(0.0, 0.0, 0.0);
+            depth = max_depth;
+            npend = 0;
+            state = ST_TRACE;
+            if (kCount) rc.samples++;
+        }
+
+        const Hit hit = cast<kAccel, PS, PB, kCount>(sm, big, v, ro, rd, cn);
+
+        bool branch_done = false;      // this TraceRay chain returned; continue with a parked branch or finish the sample
+        bool after_lights = false;
+        if (state == ST_TRACE) {
+            if (kCount) rc.trace_calls++;
+            if (hit.obj == MISS) {
+                L = L + imp * background;                                   // scene.cpp:97-100
+                branch_done = true;
+            } else {
+                const uint32_t orec = v.off_obj + hit.obj * OBJ_STRIDE;
+                const uint32_t kind = sm[orec + OBJ_KIND];
+                if (depth == 0 || kind == MCRT_OBJECT_LIGHT) {
+                    L = L + imp * ldd3(sm, orec + OBJ_EMISSION);            // scene.cpp:103-107
+                    branch_done = true;
+                } else {
+                    V3 p = ro + rd * hit.t;                                 // scene.cpp:111
+                    V3 n = surface_normal(sm, big, v, hit, p);              // scene.cpp:112
+                    const uint32_t surface = sm[orec + OBJ_SURFACE];
+                    if (surface == MCRT_SURFACE_DIFFUSE) {
+                        p = p + n * kMargin;                                // scene.cpp:115
+                        hp = p; hn = n; hd = rd; horec = orec;
+                        direct = dmk(0.0, 0.0, 0.0);
+                        light_i = 0;
+                        if (v.nlights == 0) after_lights = true;
+                        else {
+                            const uint32_t lrec = v.off_obj + sm[v.off_lights] * OBJ_STRIDE;
+                            V3 ldir = normalize(light_point(sm, lrec, g) - hp);   // scene.cpp:129-130
+                            ro = hp; rd = ldir;
+                            state = ST_SHADOW;
+                        }
+                    } else if (surface == MCRT_SURFACE_SPECULAR) {
+                        p = p + n * kMargin;                                // scene.cpp:171
+                        rd = reflect(rd, n);
+                        ro = p;
+                        depth -= 1;
+                    } else if (surface == MCRT_SURFACE_REFRACTIVE) {
+                        const V3 I = rd;
+                        float n1 = 1.0f;
+                        float n2 = ldf(sm, orec + OBJ_IOR);
+                        if (dot(n, I) >= 0) {                               // scene.cpp:183-187
+                            n = n * -1.0f;
+                            float tmp = n1; n1 = n2; n2 = tmp;
+                        }
+                        const V3 errorMargin = n * kMargin;
+                        const float nr = n1 / n2;
+                        const float cosI = dot(I, n);
+                        const float cos2t = 1.0f - nr * nr * (1.0f - cosI * cosI);
+                        if (cos2t < 0.0f) {                                 // total internal reflection, scene.cpp:194-198
+                            ro = p + errorMargin; rd = reflect(I, n); depth -= 1;
+                        } else {
+                            const V3 tdir = I * nr - n * (cosI * nr + sqrtf(cos2t));   // scene.cpp:202
+                            float R0 = (n2 - n1) / (n2 + n1);
+                            R0 *= R0;
+                            const float c = 1.0f - (-cosI);
+                            const float R = R0 + (1.0f - R0) * c * c * c * c * c;
+                            if (rng_double(g) < max_importance(imp)) {      // scene.cpp:209-214: trace both
+                                // park the reflect branch, run the refract branch first (the order g++ evaluates
+                                // the two operands of the `+` at scene.cpp:212-213; pinned by fixture F5)
+                                const V3 po = p + errorMargin, pd = reflect(I, n);
+                                const D3 pimp = imp * (double)R;
+                                *pend.at(npend, 0) = __float_as_uint(po.x); *pend.at(npend, 1) = __float_as_uint(po.y); *pend.at(npend, 2) = __float_as_uint(po.z);
+                                *pend.at(npend, 3) = __float_as_uint(pd.x); *pend.at(npend, 4) = __float_as_uint(pd.y); *pend.at(npend, 5) = __float_as_uint(pd.z);
+                                const uint64_t ix = (uint64_t)__double_as_longlong(pimp.x), iy = (uint64_t)__double_as_longlong(pimp.y), iz = (uint64_t)__double_as_longlong(pimp.z);
+                                *pend.at(npend, 6) = (uint32_t)ix; *pend.at(npend, 7) = (uint32_t)(ix >> 32);
+                                *pend.at(npend, 8) = (uint32_t)iy; *pend.at(npend, 9) = (uint32_t)(iy >> 32);
+                                *pend.at(npend, 10) = (uint32_t)iz; *pend.at(npend, 11) = (uint32_t)(iz >> 32);
+                                *pend.at(npend, 12) = depth - 1;
+                                npend += 1;
+                                if (kCount) rc.splits++;
+                                imp = imp * (double)(1.0 - R);
+                                ro = p - errorMargin; rd = tdir; depth -= 1;
+                            } else {
+                                const double P = .25 + .5 * R;              // scene.cpp:218-228
+                                if (rng_double(g) < P) {
+                                    imp = imp * (R / P);
+                                    ro = p + errorMargin; rd = reflect(I, n); depth -= 1;
+                                } else {
+                                    imp = imp * ((1.0 - R) / (1.0 - P));
+                                    ro = p - errorMargin; rd = tdir; depth -= 1;
+                                }
+                            }
+                        }
+                    } else {
+                        branch_done = true;                                 // Diffuse_Specular: black, scene.cpp:232-233
+                    }
+                }
+            }
+        } else {   // ST_SHADOW: the query was a shadow ray, scene.cpp:133-141
+            const uint32_t lobj = sm[v.off_lights + light_i];
+            if (hit.obj == MISS || hit.obj == lobj) {
+                const uint32_t lrec = v.off_obj + lobj * OBJ_STRIDE;
+                const float surfaceDot = dot(hn, rd);
+                const float lightDot = dot(mk(0.0f, -1.0f, 0.0f), rd * -1.0f);
+                const double f = brdf(sm, horec, hd, rd, hn);
+                direct = direct + ldd3(sm, lrec + OBJ_EMISSION) * (double)(f * surfaceDot * lightDot);
+            }
+            light_i += 1;
+            if (light_i < v.nlights) {
+                const uint32_t lrec = v.off_obj + sm[v.off_lights + light_i] * OBJ_STRIDE;
+                V3 ldir = normalize(light_point(sm, lrec, g) - hp);
+                ro = hp; rd = ldir;
+            } else after_lights = true;
+        }
+
+        if (after_lights) {
+            // Russian roulette and the diffuse bounce, scene.cpp:147-167
+            const double p = max_importance(imp);
+            imp = imp * ldd3(sm, horec + OBJ_COLOR);
+            direct = direct * imp;
+            L = L + direct;
+            if ((0.0 + (1.0 - 0.0) * rng_double(g)) > p) branch_done = true;
+            else {
+                imp = ddivs(imp, p);
+                float cosTheta;
+                const V3 bounce = hemisphere(hn, g, cosTheta);
+                imp = imp * (2.0 * (double)cosTheta * brdf(sm, horec, hd, bounce, hn));
+                ro = hp; rd = bounce; depth -= 1;
+                state = ST_TRACE;
+            }
+        }
+
+        if (branch_done) {
+            if (npend > 0) {
+                npend -= 1;
+                ro = mk(__uint_as_float(*pend.at(npend, 0)), __uint_as_float(*pend.at(npend, 1)), __uint_as_float(*pend.at(npend, 2)));
+                rd = mk(__uint_as_float(*pend.at(npend, 3)), __uint_as_float(*pend.at(npend, 4)), __uint_as_float(*pend.at(npend, 5)));
+                const uint64_t ix = (uint64_t)*pend.at(npend, 6) | ((uint64_t)*pend.at(npend, 7) << 32);
+                const uint64_t iy = (uint64_t)*pend.at(npend, 8) | ((uint64_t)*pend.at(npend, 9) << 32);
+                const uint64_t iz = (uint64_t)*pend.at(npend, 10) | ((uint64_t)*pend.at(npend, 11) << 32);
+                imp = dmk(__longlong_as_double((long long)ix), __longlong_as_double((long long)iy), __longlong_as_double((long long)iz));
+                depth = *pend.at(npend, 12);
+                state = ST_TRACE;
+            } else {
+                // PixelBuffer::Accumulate, source/core/pixelbuffer.cpp:39-46 (non-finite samples dropped)
+                const bool fin = isfinite(L.x) && isfinite(L.y) && isfinite(L.z);
+                if (fin || keep_nonfinite) sum = sum + L;
+                else dropped += 1;
+                k += 1;
+                state = (k < s_count) ? ST_NEW : ST_DONE;
+            }
+        }
+    }
+}
+
+struct RenderArgs {
+    SceneView view;
+    CameraDev cam;
+    double* accum;
+    uint32_t* tile_counter;     // [0] next tile, [1] dropped samples
+    unsigned long long* counters;   // 8 x u64 (kCount builds)
+    uint32_t* pend;
+    uint32_t s_begin, s_count, max_depth;
+    uint32_t tiles_x, tiles;
+    uint64_t seed;
+};
+
+__device__ __forceinline__ void flush_counters(unsigned long long* out, const Counters& cn, const RenderCounters& rc)
+{
+    atomicAdd(out + 0, (unsigned long long)cn.rays);
+    atomicAdd(out + 1, (unsigned long long)cn.nodes);
+    atomicAdd(out + 2, (unsigned long long)cn.tris);
+    atomicAdd(out + 3, (unsigned long long)cn.spheres);
+    atomicAdd(out + 4, (unsigned long long)cn.gates);
+    atomicAdd(out + 5, (unsigned long long)rc.samples);
+    atomicAdd(out + 6, (unsigned long long)rc.trace_calls);
+    atomicAdd(out + 7, (unsigned long long)rc.splits);
+}
+
+template <bool kBigLds, int kAccel, bool kCount>
+__global__ __launch_bounds__(kBlock) void k_render(const RenderArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    stage_scene<kBigLds>(a.view, smem);
+    const LdsPtr sm = (LdsPtr)smem;
+    const typename BigPtr<kBigLds>::type big = big_ptr<kBigLds>(a.view, smem);
+
+    PendStack pend;
+    pend.base = a.pend;
+    pend.lanes = gridDim.x * blockDim.x;
+    pend.lane = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    Counters cn = { 0, 0, 0, 0, 0 };
+    RenderCounters rc = { 0, 0, 0 };
+    uint32_t dropped_total = 0;
+
+    for (;;) {
+        // every wavefront pulls its own 8x8 tile; exit when the counter runs past the last tile
+        uint32_t tile = 0;
+        if (lane == 0) tile = atomicAdd(a.tile_counter, 1u);
+        tile = (uint32_t)__shfl((int)tile, 0);
+        if (tile >= a.tiles) break;
+        const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+        const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+        const bool inside = x < a.cam.width && y < a.cam.height;
+        const uint32_t pixel = inside ? y * a.cam.width + x : 0u;
+        D3 sum; uint32_t dropped;
+        trace_lane<LdsPtr, typename BigPtr<kBigLds>::type, kAccel, kCount>(sm, big, a.view, a.cam, pixel, a.s_begin, inside ? a.s_count : 0u,
+                                                                          a.seed, a.max_depth, pend, false, sum, dropped, cn, rc);
+        if (inside) {
+            double* px = a.accum + (size_t)pixel * 3;
+            px[0] += sum.x; px[1] += sum.y; px[2] += sum.z;
+        }
+        dropped_total += dropped;
+    }
+    if (dropped_total) atomicAdd(a.tile_counter + 1, dropped_total);
+    if (kCount) flush_counters(a.counters, cn, rc);
+}
+
+struct ListArgs {
+    SceneView view;
+    CameraDev cam;
+    const uint32_t* pixels;
+    const uint32_t* samples;
+    double* out;
+    unsigned long long* counters;
+    uint32_t* pend;
+    uint64_t n;
+    uint32_t max_depth;
+    uint64_t seed;
+};
+
+template <bool kBigLds, int kAccel, bool kCount>
+__global__ __launch_bounds__(kBlock) void k_trace_list(const ListArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    stage_scene<kBigLds>(a.view, smem);
+    const LdsPtr sm = (LdsPtr)smem;
+    const typename BigPtr<kBigLds>::type big = big_ptr<kBigLds>(a.view, smem);
+    PendStack pend;
+    pend.base = a.pend;
+    pend.lanes = gridDim.x * blockDim.x;
+    pend.lane = blockIdx.x * blockDim.x + threadIdx.x;
+    Counters cn = { 0, 0, 0, 0, 0 };
+    RenderCounters rc = { 0, 0, 0 };
+    for (uint64_t i = pend.lane; i < a.n; i += pend.lanes) {
+        D3 sum; uint32_t dropped;
+        trace_lane<LdsPtr, typename BigPtr<kBigLds>::type, kAccel, kCount>(sm, big, a.view, a.cam, a.pixels[i], a.samples[i], 1u, a.seed,
+                                                                          a.max_depth, pend, true, sum, dropped, cn, rc);
+        a.out[3 * i] = sum.x; a.out[3 * i + 1] = sum.y; a.out[3 * i + 2] = sum.z;
+    }
+    if (kCount) flush_counters(a.counters, cn, rc);
+}
+
+template <bool kBigLds, int kAccel, bool kCount>
+__global__ __launch_bounds__(kBlock) void k_intersect(const SceneView v, uint64_t n, const float* __restrict__ o, const float* __restrict__ d,
+                                                      int32_t* __restrict__ out_obj, uint32_t* __restrict__ out_elem, float* __restrict__ out_t,
+                                                      unsigned long long* counters)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    stage_scene<kBigLds>(v, smem);
+    const LdsPtr sm = (LdsPtr)smem;
+    const typename BigPtr<kBigLds>::type big = big_ptr<kBigLds>(v, smem);
+    Counters cn = { 0, 0, 0, 0, 0 };
+    RenderCounters rc = { 0, 0, 0 };
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const V3 ro = mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+        const V3 rd = mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        const Hit h = cast<kAccel, LdsPtr, typename BigPtr<kBigLds>::type, kCount>(sm, big, v, ro, rd, cn);
+        out_obj[i] = (h.obj == MISS) ? -1 : (int32_t)h.obj;
+        out_elem[i] = h.elem;
+        out_t[i] = h.t;
+    }
+    if (kCount) flush_counters(counters, cn, rc);
+}
+
+__global__ __launch_bounds__(kBlock) void k_camera_rays(const CameraDev cam, uint64_t n, const float* __restrict__ xs, const float* __restrict__ ys,
+                                                        float* __restrict__ out_o, float* __restrict__ out_d)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        V3 o, d;
+        camera_ray(cam, xs[i], ys[i], o, d);
+        out_o[3 * i] = o.x; out_o[3 * i + 1] = o.y; out_o[3 * i + 2] = o.z;
+        out_d[3 * i] = d.x; out_d[3 * i + 1] = d.y; out_d[3 * i + 2] = d.z;
+    }
+}
+
+template <bool kBigLds, int kAccel>
+__global__ __launch_bounds__(kBlock) void k_unlit(const SceneView v, const CameraDev cam, double* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    stage_scene<kBigLds>(v, smem);
+    const LdsPtr sm = (LdsPtr)smem;
+    const typename BigPtr<kBigLds>::type big = big_ptr<kBigLds>(v, smem);
+    Counters cn = { 0, 0, 0, 0, 0 };
+    const uint64_t npix = (uint64_t)cam.width * cam.height;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+        const uint32_t x = (uint32_t)(i % cam.width), y = (uint32_t)(i / cam.width);
+        V3 o, d;
+        camera_ray(cam, (float)x + 0.5f, (float)y + 0.5f, o, d);     // source/main.cpp:126
+        const Hit h = cast<kAccel, LdsPtr, typename BigPtr<kBigLds>::type, false>(sm, big, v, o, d, cn);
+        D3 c = dmk(0.0, 0.0, 0.0);
+        if (h.obj != MISS) c = ldd3(sm, v.off_obj + h.obj * OBJ_STRIDE + OBJ_COLOR);
+        out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+    }
+}
+
+// source/main.cpp:142-164 + GLImageBuffer::SetPixel (source/opengl/data.cpp:28-50)
+__global__ __launch_bounds__(kBlock) void k_resolve(const double* __restrict__ sums, uint64_t npix, double spp, int tonemap, double inv_gamma,
+                                                    double exposure, uint8_t* __restrict__ out_bgra, double* __restrict__ out_mean)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += stride) {
+        double c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double x = sums[3 * p + k] / spp;
+            if (out_mean) out_mean[3 * p + k] = x;
+            if (tonemap == MCRT_TONEMAP_REINHARD) {
+                x = x / (x + 1.0);
+                x = pow(x, inv_gamma);
+            } else if (tonemap == MCRT_TONEMAP_EXPOSURE) {
+                x = 1.0 - exp(-x * exposure);
+                x = pow(x, inv_gamma);
+            }
+            double t = (x < 1.0) ? x : 1.0;
+            t = (t < 0.0) ? 0.0 : t;
+            c[k] = t;
+        }
+        if (out_bgra) {
+            uchar4 px;
+            px.x = (unsigned char)(c[2] * 255.0);
+            px.y = (unsigned char)(c[1] * 255.0);
+            px.z = (unsigned char)(c[0] * 255.0);
+            px.w = (unsigned char)(1.0 * 255.0);
+            reinterpret_cast<uchar4*>(out_bgra)[p] = px;
+        }
+    }
+}
+
+thread_local std::string g_create_error;
+
+} // namespace
+
+// ===================================================================== context
+struct mcrt_ctx {
+    int device = 0;
+    int cu_count = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    FlatScene flat;
+    SceneView view{};
+    uint32_t* d_small = nullptr;
+    uint32_t* d_big = nullptr;
+    bool have_scene = false;
+    bool big_in_lds = false;
+    size_t lds_bytes = 0;
+
+    CameraDev cam{};
+    bool have_camera = false;
+    double* d_accum_own = nullptr;
+    size_t accum_pixels = 0;
+    double* d_accum = nullptr;
+
+    int accel = MCRT_ACCEL_OCTREE;
+    bool counting = false;
+    unsigned long long* d_counters = nullptr;   // 8 x u64
+    uint32_t* d_tile = nullptr;                 // 2 x u32
+    uint32_t* d_pend = nullptr;
+    size_t pend_words = 0;
+    uint32_t grid_blocks = 0;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+
+namespace {
+
+int fail(mcrt_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return fail(ctx, MCRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int bind_device(mcrt_ctx* c) { HIP_TRY(c, hipSetDevice(c->device)); return MCRT_OK; }
+
+// persistent grid: enough 256-lane workgroups to fill every CU at the occupancy the kernel can reach
+uint32_t grid_for(const mcrt_ctx* c) { return (uint32_t)c->cu_count * 8u; }
+
+int ensure_pend(mcrt_ctx* c, uint32_t max_depth)
+{
+    const uint32_t entries = std::max(1u, max_depth);
+    const size_t lanes = (size_t)grid_for(c) * kBlock;
+    const size_t words = lanes * kPendFields * entries;
+    if (words > c->pend_words) {
+        if (c->d_pend) { HIP_TRY(c, hipFree(c->d_pend)); c->d_pend = nullptr; c->pend_words = 0; }
+        HIP_TRY(c, hipMalloc(&c->d_pend, words * sizeof(uint32_t)));
+        c->pend_words = words;
+    }
+    return MCRT_OK;
+}
+
+template <class K> int set_lds_limit(mcrt_ctx* c, K kernel, size_t bytes)
+{
+    if (bytes > 48 * 1024) HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return MCRT_OK;
+}
+
+template <bool kBigLds, int kAccel, bool kCount> int launch_render_t(mcrt_ctx* c, const RenderArgs& a)
+{
+    auto kern = k_render<kBigLds, kAccel, kCount>;
+    int rc = set_lds_limit(c, kern, c->lds_bytes);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid_for(c)), dim3(kBlock), c->lds_bytes, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    return MCRT_OK;
+}
+template <bool kBigLds, int kAccel, bool kCount> int launch_list_t(mcrt_ctx* c, const ListArgs& a)
+{
+    auto kern = k_trace_list<kBigLds, kAccel, kCount>;
+    int rc = set_lds_limit(c, kern, c->lds_bytes);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid_for(c)), dim3(kBlock), c->lds_bytes, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    return MCRT_OK;
+}
+template <bool kBigLds, int kAccel, bool kCount>
+int launch_intersect_t(mcrt_ctx* c, uint64_t n, const float* o, const float* d, int32_t* obj, uint32_t* elem, float* t)
+{
+    auto kern = k_intersect<kBigLds, kAccel, kCount>;
+    int rc = set_lds_limit(c, kern, c->lds_bytes);
+    if (rc) return rc;
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)grid_for(c) * 4);
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kBlock), c->lds_bytes, c->stream, c->view, n, o, d, obj, elem, t, c->d_counters);
+    HIP_TRY(c, hipGetLastError());
+    return MCRT_OK;
+}
+template <bool kBigLds, int kAccel> int launch_unlit_t(mcrt_ctx* c, double* out)
+{
+    auto kern = k_unlit<kBigLds, kAccel>;
+    int rc = set_lds_limit(c, kern, c->lds_bytes);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid_for(c)), dim3(kBlock), c->lds_bytes, c->stream, c->view, c->cam, out);
+    HIP_TRY(c, hipGetLastError());
+    return MCRT_OK;
+}
+
+// Dispatch on (scene residency, accel mode, counting).  Counting builds exist for the octree only.
+#define MCRT_DISPATCH(c, CALL_, ...)                                                                                   \
+    do {                                                                                                                \
+        const bool lds_ = (c)->big_in_lds;                                                                              \
+        if ((c)->accel == MCRT_ACCEL_BRUTE) {                                                                           \
+            if ((c)->counting) return lds_ ? CALL_<true, MCRT_ACCEL_BRUTE, true>(__VA_ARGS__) : CALL_<false, MCRT_ACCEL_BRUTE, true>(__VA_ARGS__);   \
+            return lds_ ? CALL_<true, MCRT_ACCEL_BRUTE, false>(__VA_ARGS__) : CALL_<false, MCRT_ACCEL_BRUTE, false>(__VA_ARGS__);                    \
+        }                                                                                                               \
+        if ((c)->counting) return lds_ ? CALL_<true, MCRT_ACCEL_OCTREE, true>(__VA_ARGS__) : CALL_<false, MCRT_ACCEL_OCTREE, true>(__VA_ARGS__);     \
+        return lds_ ? CALL_<true, MCRT_ACCEL_OCTREE, false>(__VA_ARGS__) : CALL_<false, MCRT_ACCEL_OCTREE, false>(__VA_ARGS__);                      \
+    } while (0)
+
+int launch_render(mcrt_ctx* c, const RenderArgs& a) { MCRT_DISPATCH(c, launch_render_t, c, a); }
+int launch_list(mcrt_ctx* c, const ListArgs& a) { MCRT_DISPATCH(c, launch_list_t, c, a); }
+int launch_intersect(mcrt_ctx* c, uint64_t n, const float* o, const float* d, int32_t* obj, uint32_t* elem, float* t)
+{
+    MCRT_DISPATCH(c, launch_intersect_t, c, n, o, d, obj, elem, t);
+}
+int launch_unlit(mcrt_ctx* c, double* out)
+{
+    if (c->accel == MCRT_ACCEL_BRUTE) return c->big_in_lds ? launch_unlit_t<true, MCRT_ACCEL_BRUTE>(c, out) : launch_unlit_t<false, MCRT_ACCEL_BRUTE>(c, out);
+    return c->big_in_lds ? launch_unlit_t<true, MCRT_ACCEL_OCTREE>(c, out) : launch_unlit_t<false, MCRT_ACCEL_OCTREE>(c, out);
+}
+
+int need_scene(mcrt_ctx* c, bool camera)
+{
+    if (!c) return MCRT_ERR_INVALID;
+    if (!c->have_scene) return fail(c, MCRT_ERR_STATE, "no scene uploaded (mcrt_upload_scene)");
+    if (camera && !c->have_camera) return fail(c, MCRT_ERR_STATE, "no camera set (mcrt_set_camera)");
+    return bind_device(c);
+}
+
+template <class T> struct DevBuf {
+    T* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+} // namespace
+
+// ======================================================================== ABI
+extern "C" {
+
+int mcrt_create(int device_id, mcrt_ctx** out_ctx)
+{
+    if (!out_ctx) return fail(nullptr, MCRT_ERR_INVALID, "out_ctx is null");
+    *out_ctx = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return fail(nullptr, MCRT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= count) return fail(nullptr, MCRT_ERR_NO_DEVICE, "device_id out of range");
+    mcrt_ctx* c = new (std::nothrow) mcrt_ctx;
+    if (!c) return fail(nullptr, MCRT_ERR_INVALID, "out of host memory");
+    c->device = device_id;
+    auto bail = [&](const char* what, hipError_t err) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+        mcrt_destroy(c);
+        return MCRT_ERR_HIP;
+    };
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    c->stream = c->own_stream;
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&c->d_tile, 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+    *out_ctx = c;
+    return MCRT_OK;
+}
+
+int mcrt_destroy(mcrt_ctx* c)
+{
+    if (!c) return MCRT_OK;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->d_small) (void)hipFree(c->d_small);
+    if (c->d_big) (void)hipFree(c->d_big);
+    if (c->d_accum_own) (void)hipFree(c->d_accum_own);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_tile) (void)hipFree(c->d_tile);
+    if (c->d_pend) (void)hipFree(c->d_pend);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return MCRT_OK;
+}
+
+const char* mcrt_last_error(const mcrt_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int mcrt_set_stream(mcrt_ctx* c, void* hip_stream)
+{
+    if (!c) return MCRT_ERR_INVALID;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return MCRT_OK;
+}
+
+int mcrt_upload_scene(mcrt_ctx* c, const mcrt_scene_desc* scene, const mcrt_accel_params* accel)
+{
+    if (!c) return MCRT_ERR_INVALID;
+    int rc = bind_device(c);
+    if (rc) return rc;
+    FlatScene flat;
+    std::string err;
+    rc = flatten_scene(scene, accel, flat, err);
+    if (rc) return fail(c, rc, err);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_small) { HIP_TRY(c, hipFree(c->d_small)); c->d_small = nullptr; }
+    if (c->d_big) { HIP_TRY(c, hipFree(c->d_big)); c->d_big = nullptr; }
+    c->have_scene = false;
+    HIP_TRY(c, hipMalloc(&c->d_small, std::max<size_t>(flat.small_img.size(), 1) * 4));
+    HIP_TRY(c, hipMalloc(&c->d_big, std::max<size_t>(flat.big_img.size(), 1) * 4));
+    HIP_TRY(c, hipMemcpy(c->d_small, flat.small_img.data(), flat.small_img.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_big, flat.big_img.data(), flat.big_img.size() * 4, hipMemcpyHostToDevice));
+    c->flat = std::move(flat);
+    c->view = c->flat.view;
+    c->view.small_img = c->d_small;
+    c->view.big_img = c->d_big;
+    const size_t small_bytes = (((size_t)c->view.small_words + 3u) & ~size_t(3)) * 4;
+    const size_t all_bytes = small_bytes + (size_t)c->view.big_words * 4;
+    if (small_bytes > kLdsBudgetBytes) return fail(c, MCRT_ERR_LIMIT, "object table does not fit the LDS budget");
+    c->big_in_lds = all_bytes <= kLdsBudgetBytes;
+    c->lds_bytes = c->big_in_lds ? all_bytes : small_bytes;
+    c->have_scene = true;
+    return MCRT_OK;
+}
+
+int mcrt_set_camera(mcrt_ctx* c, const mcrt_camera* cam)
+{
+    if (!c || !cam) return MCRT_ERR_INVALID;
+    if (cam->width == 0 || cam->height == 0 || (uint64_t)cam->width * cam->height > 0x7FFFFFFFull / 3) return fail(c, MCRT_ERR_INVALID, "bad image size");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    CameraDev& d = c->cam;
+    for (int i = 0; i < 3; ++i) d.pos[i] = cam->position[i];
+    d.fov_scale = cam->fov_scale;
+    for (int i = 0; i < 16; ++i) d.view[i] = cam->view[i];
+    d.width = cam->width; d.height = cam->height;
+    // PixelBuffer ctor, source/core/pixelbuffer.cpp:20-22
+    d.dx = 2.0 / (double)cam->width;
+    d.dy = 2.0 / (double)cam->height;
+    d.aspect_f = (float)(cam->width / (double)cam->height);
+    const size_t px = (size_t)cam->width * cam->height;
+    if (px != c->accum_pixels) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->d_accum_own) { HIP_TRY(c, hipFree(c->d_accum_own)); c->d_accum_own = nullptr; }
+        HIP_TRY(c, hipMalloc(&c->d_accum_own, px * 3 * sizeof(double)));
+        c->accum_pixels = px;
+        c->d_accum = c->d_accum_own;
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_accum_own, 0, px * 3 * sizeof(double), c->stream));
+    c->have_camera = true;
+    return MCRT_OK;
+}
+
+int mcrt_set_accel(mcrt_ctx* c, int mode)
+{
+    if (!c) return MCRT_ERR_INVALID;
+    if (mode != MCRT_ACCEL_OCTREE && mode != MCRT_ACCEL_BRUTE) return fail(c, MCRT_ERR_INVALID, "unknown accel mode");
+    c->accel = mode;
+    return MCRT_OK;
+}
+
+int mcrt_camera_rays(mcrt_ctx* c, uint64_t n, const float* xs, const float* ys, float* out_o, float* out_d)
+{
+    if (!c) return MCRT_ERR_INVALID;
+    if (!c->have_camera) return fail(c, MCRT_ERR_STATE, "no camera set (mcrt_set_camera)");
+    if (n == 0) return MCRT_OK;
+    if (!xs || !ys || !out_o || !out_d) return fail(c, MCRT_ERR_INVALID, "null buffer");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    DevBuf<float> dx, dy, dor, ddi;
+    HIP_TRY(c, hipMalloc(&dx.p, n * 4)); HIP_TRY(c, hipMalloc(&dy.p, n * 4));
+    HIP_TRY(c, hipMalloc(&dor.p, n * 12)); HIP_TRY(c, hipMalloc(&ddi.p, n * 12));
+    HIP_TRY(c, hipMemcpyAsync(dx.p, xs, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dy.p, ys, n * 4, hipMemcpyHostToDevice, c->stream));
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((n + kBlock - 1) / kBlock, 65535);
+    hipLaunchKernelGGL(k_camera_rays, dim3(blocks), dim3(kBlock), 0, c->stream, c->cam, n, dx.p, dy.p, dor.p, ddi.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out_o, dor.p, n * 12, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out_d, ddi.p, n * 12, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+
+int mcrt_intersect_device(mcrt_ctx* c, uint64_t n, const float* d_o, const float* d_d, int32_t* d_obj, uint32_t* d_elem, float* d_t)
+{
+    int rc = need_scene(c, false);
+    if (rc) return rc;
+    if (n == 0) return MCRT_OK;
+    if (!d_o || !d_d || !d_obj || !d_elem || !d_t) return fail(c, MCRT_ERR_INVALID, "null buffer");
+    if (c->counting) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    return launch_intersect(c, n, d_o, d_d, d_obj, d_elem, d_t);
+}
+
+int mcrt_intersect(mcrt_ctx* c, uint64_t n, const float* o, const float* d, int32_t* out_obj, uint32_t* out_elem, float* out_t)
+{
+    int rc = need_scene(c, false);
+    if (rc) return rc;
+    if (n == 0) return MCRT_OK;
+    if (!o || !d || !out_obj || !out_elem || !out_t) return fail(c, MCRT_ERR_INVALID, "null buffer");
+    DevBuf<float> dor, ddi, dt;
+    DevBuf<int32_t> dobj;
+    DevBuf<uint32_t> delem;
+    HIP_TRY(c, hipMalloc(&dor.p, n * 12)); HIP_TRY(c, hipMalloc(&ddi.p, n * 12)); HIP_TRY(c, hipMalloc(&dt.p, n * 4));
+    HIP_TRY(c, hipMalloc(&dobj.p, n * 4)); HIP_TRY(c, hipMalloc(&delem.p, n * 4));
+    HIP_TRY(c, hipMemcpyAsync(dor.p, o, n * 12, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(ddi.p, d, n * 12, hipMemcpyHostToDevice, c->stream));
+    rc = mcrt_intersect_device(c, n, dor.p, ddi.p, dobj.p, delem.p, dt.p);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out_obj, dobj.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out_elem, delem.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out_t, dt.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+
+int mcrt_trace_samples(mcrt_ctx* c, uint64_t n, const uint32_t* pixels, const uint32_t* samples, uint64_t seed, uint32_t max_depth, double* out)
+{
+    int rc = need_scene(c, true);
+    if (rc) return rc;
+    if (n == 0) return MCRT_OK;
+    if (!pixels || !samples || !out) return fail(c, MCRT_ERR_INVALID, "null buffer");
+    if (max_depth > kMaxDepthLimit) return fail(c, MCRT_ERR_LIMIT, "max_depth above 256");
+    const uint64_t npix = (uint64_t)c->cam.width * c->cam.height;
+    for (uint64_t i = 0; i < n; ++i)
+        if (pixels[i] >= npix) return fail(c, MCRT_ERR_INVALID, "pixel index outside the image");
+    rc = ensure_pend(c, max_depth);
+    if (rc) return rc;
+    DevBuf<uint32_t> dp, ds;
+    DevBuf<double> dout;
+    HIP_TRY(c, hipMalloc(&dp.p, n * 4)); HIP_TRY(c, hipMalloc(&ds.p, n * 4)); HIP_TRY(c, hipMalloc(&dout.p, n * 24));
+    HIP_TRY(c, hipMemcpyAsync(dp.p, pixels, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(ds.p, samples, n * 4, hipMemcpyHostToDevice, c->stream));
+    if (c->counting) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    ListArgs a;
+    a.view = c->view; a.cam = c->cam; a.pixels = dp.p; a.samples = ds.p; a.out = dout.p; a.counters = c->d_counters; a.pend = c->d_pend;
+    a.n = n; a.max_depth = max_depth; a.seed = seed;
+    rc = launch_list(c, a);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out, dout.p, n * 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+
+int mcrt_render_unlit(mcrt_ctx* c, double* out)
+{
+    int rc = need_scene(c, true);
+    if (rc) return rc;
+    if (!out) return fail(c, MCRT_ERR_INVALID, "null buffer");
+    const size_t bytes = c->accum_pixels * 3 * sizeof(double);
+    DevBuf<double> d;
+    HIP_TRY(c, hipMalloc(&d.p, bytes));
+    rc = launch_unlit(c, d.p);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out, d.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+
+void mcrt_rng_seed(uint64_t seed, uint32_t pixel, uint32_t sample, uint64_t out_state[2])
+{
+    uint64_t a, b;
+    sample_seed(seed, pixel, sample, a, b);
+    out_state[0] = a; out_state[1] = b;
+}
+
+int mcrt_clear(mcrt_ctx* c)
+{
+    if (!c) return MCRT_ERR_INVALID;
+    if (!c->have_camera) return fail(c, MCRT_ERR_STATE, "no camera set (mcrt_set_camera)");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, c->accum_pixels * 3 * sizeof(double), c->stream));
+    return MCRT_OK;
+}
+
+int mcrt_bind_accumulator(mcrt_ctx* c, double* d_accum)
+{
+    if (!c) return MCRT_ERR_INVALID;
+    if (!c->have_camera) return fail(c, MCRT_ERR_STATE, "no camera set (mcrt_set_camera)");
+    c->d_accum = d_accum ? d_accum : c->d_accum_own;
+    return MCRT_OK;
+}
+
+int mcrt_accumulator(mcrt_ctx* c, double** out)
+{
+    if (!c || !out) return MCRT_ERR_INVALID;
+    if (!c->have_camera) return fail(c, MCRT_ERR_STATE, "no camera set (mcrt_set_camera)");
+    *out = c->d_accum;
+    return MCRT_OK;
+}
+
+int mcrt_render(mcrt_ctx* c, uint32_t sample_begin, uint32_t sample_count, uint32_t max_depth, uint64_t seed)
+{
+    int rc = need_scene(c, true);
+    if (rc) return rc;
+    if (max_depth > kMaxDepthLimit) return fail(c, MCRT_ERR_LIMIT, "max_depth above 256");
+    if (sample_count == 0) return MCRT_OK;
+    rc = ensure_pend(c, max_depth);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->d_tile, 0, 2 * sizeof(uint32_t), c->stream));
+    if (c->counting) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    RenderArgs a;
+    a.view = c->view; a.cam = c->cam; a.accum = c->d_accum; a.tile_counter = c->d_tile; a.counters = c->d_counters; a.pend = c->d_pend;
+    a.s_begin = sample_begin; a.s_count = sample_count; a.max_depth = max_depth;
+    a.tiles_x = (c->cam.width + 7u) / 8u;
+    a.tiles = a.tiles_x * ((c->cam.height + 7u) / 8u);
+    a.seed = seed;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    rc = launch_render(c, a);
+    if (rc) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    return MCRT_OK;
+}
+
+int mcrt_last_render_ms(mcrt_ctx* c, float* out_ms)
+{
+    if (!c || !out_ms) return MCRT_ERR_INVALID;
+    if (!c->timed) return fail(c, MCRT_ERR_STATE, "no render launched yet");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    HIP_TRY(c, hipEventElapsedTime(out_ms, c->ev0, c->ev1));
+    return MCRT_OK;
+}
+
+int mcrt_resolve(mcrt_ctx* c, int tonemap, double gamma, double exposure, uint64_t spp_total, uint8_t* out_bgra8, double* out_mean)
+{
+    if (!c) return MCRT_ERR_INVALID;
+    if (!c->have_camera) return fail(c, MCRT_ERR_STATE, "no camera set (mcrt_set_camera)");
+    if (tonemap < MCRT_TONEMAP_NONE || tonemap > MCRT_TONEMAP_EXPOSURE) return fail(c, MCRT_ERR_INVALID, "unknown tonemap");
+    if (spp_total == 0) return fail(c, MCRT_ERR_INVALID, "spp_total is zero");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    const uint64_t npix = c->accum_pixels;
+    DevBuf<uint8_t> dimg;
+    DevBuf<double> dmean;
+    if (out_bgra8) HIP_TRY(c, hipMalloc(&dimg.p, npix * 4));
+    if (out_mean) HIP_TRY(c, hipMalloc(&dmean.p, npix * 24));
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((npix + kBlock - 1) / kBlock, 65535);
+    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(kBlock), 0, c->stream, (const double*)c->d_accum, npix, (double)spp_total, tonemap,
+                       1.0 / gamma, exposure, dimg.p, dmean.p);
+    HIP_TRY(c, hipGetLastError());
+    if (out_bgra8) HIP_TRY(c, hipMemcpyAsync(out_bgra8, dimg.p, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    if (out_mean) HIP_TRY(c, hipMemcpyAsync(out_mean, dmean.p, npix * 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+
+int mcrt_read_accumulator(mcrt_ctx* c, double* out)
+{
+    if (!c || !out) return MCRT_ERR_INVALID;
+    if (!c->have_camera) return fail(c, MCRT_ERR_STATE, "no camera set (mcrt_set_camera)");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_accum, c->accum_pixels * 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+
+int mcrt_synchronize(mcrt_ctx* c)
+{
+    if (!c) return MCRT_ERR_INVALID;
+    int rc = bind_device(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+
+int mcrt_octree_info_get(mcrt_ctx* c, mcrt_octree_info* out)
+{
+    if (!c || !out) return MCRT_ERR_INVALID;
+    if (!c->have_scene) return fail(c, MCRT_ERR_STATE, "no scene uploaded (mcrt_upload_scene)");
+    out->node_count = c->view.nnode;
+    out->prim_ref_count = c->flat.ref_count;
+    out->prim_count = c->view.nprim;
+    out->max_depth = c->flat.tree_depth;
+    out->blob_bytes = (c->view.small_words + c->view.big_words) * 4;
+    out->lds_resident = c->big_in_lds ? 1u : 0u;
+    return MCRT_OK;
+}
+
+int mcrt_octree_download(mcrt_ctx* c, float* node_box, uint32_t* node_words, uint32_t* prim_refs)
+{
+    if (!c) return MCRT_ERR_INVALID;
+    if (!c->have_scene) return fail(c, MCRT_ERR_STATE, "no scene uploaded (mcrt_upload_scene)");
+    if (node_box) std::memcpy(node_box, c->flat.node_box.data(), c->flat.node_box.size() * 4);
+    if (node_words) std::memcpy(node_words, c->flat.node_words.data(), c->flat.node_words.size() * 4);
+    if (prim_refs) std::memcpy(prim_refs, c->flat.refs.data(), c->flat.refs.size() * 4);
+    return MCRT_OK;
+}
+
+int mcrt_scene_image_create(const mcrt_scene_desc* scene, const mcrt_accel_params* accel, mcrt_scene_image** out_image)
+{
+    if (!out_image) return fail(nullptr, MCRT_ERR_INVALID, "out_image is null");
+    *out_image = nullptr;
+    FlatScene* f = new (std::nothrow) FlatScene;
+    if (!f) return fail(nullptr, MCRT_ERR_INVALID, "out of host memory");
+    std::string err;
+    int rc = flatten_scene(scene, accel, *f, err);
+    if (rc) { delete f; return fail(nullptr, rc, err); }
+    *out_image = reinterpret_cast<mcrt_scene_image*>(f);
+    return MCRT_OK;
+}
+
+int mcrt_scene_image_destroy(mcrt_scene_image* image)
+{
+    delete reinterpret_cast<FlatScene*>(image);
+    return MCRT_OK;
+}
+
+int mcrt_scene_image_info(const mcrt_scene_image* image, mcrt_octree_info* out)
+{
+    if (!image || !out) return fail(nullptr, MCRT_ERR_INVALID, "null argument");
+    const FlatScene& f = *reinterpret_cast<const FlatScene*>(image);
+    out->node_count = f.view.nnode;
+    out->prim_ref_count = f.ref_count;
+    out->prim_count = f.view.nprim;
+    out->max_depth = f.tree_depth;
+    out->blob_bytes = (f.view.small_words + f.view.big_words) * 4;
+    const size_t small_bytes = (((size_t)f.view.small_words + 3u) & ~size_t(3)) * 4;
+    out->lds_resident = (small_bytes + (size_t)f.view.big_words * 4 <= kLdsBudgetBytes) ? 1u : 0u;
+    return MCRT_OK;
+}
+
+int mcrt_scene_image_octree(const mcrt_scene_image* image, float* node_box, uint32_t* node_words, uint32_t* prim_refs)
+{
+    if (!image) return fail(nullptr, MCRT_ERR_INVALID, "null argument");
+    const FlatScene& f = *reinterpret_cast<const FlatScene*>(image);
+    if (node_box) std::memcpy(node_box, f.node_box.data(), f.node_box.size() * 4);
+    if (node_words) std::memcpy(node_words, f.node_words.data(), f.node_words.size() * 4);
+    if (prim_refs) std::memcpy(prim_refs, f.refs.data(), f.refs.size() * 4);
+    return MCRT_OK;
+}
+
+int mcrt_set_counting(mcrt_ctx* c, int enabled)
+{
+    if (!c) return MCRT_ERR_INVALID;
+    c->counting = enabled != 0;
+    return MCRT_OK;
+}
+
+int mcrt_counters(mcrt_ctx* c, uint64_t out[8])
+{
+    if (!c || !out) return MCRT_ERR_INVALID;
+    int rc = bind_device(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long tmp[8];
+    HIP_TRY(c, hipMemcpy(tmp, c->d_counters, sizeof tmp, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) out[i] = tmp[i];
+    return MCRT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,531 @@
+// mcrt_device.h - device-side arithmetic of the path tracer (gfx950).
+//
+// Everything here is compiled with -ffp-contract=off: every float / double
+// operation is a single correctly rounded IEEE operation in the order the
+// reference performs it, so hit indices, hit distances and per-sample radiance
+// can be compared bit for bit with the CPU.  Citations are to the reference
+// checkout (source/...) and its vendored glm (include/glm/...).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mcrt_layout.h"
+
+namespace mcrt {
+
+#define MCRT_DEV __device__ __forceinline__
+
+constexpr float kFltEpsilon = 1.1920928955078125e-07f;     // FLT_EPSILON
+constexpr float kFltMax = 3.402823466e+38f;                 // FLOAT_INFINITY, source/core/math.h:32
+constexpr float kMargin = kFltEpsilon * 20.0f;              // INTERSECTION_ERROR_MARGIN, source/core/math.h:34
+constexpr float kTwoPiF = (float)6.28318530717958647692528676655900576;  // float(M_TWO_PI), source/core/math.h:24-26
+
+// ------------------------------------------------------------------ vectors
+struct V3 { float x, y, z; };
+struct D3 { double x, y, z; };
+
+MCRT_DEV V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+MCRT_DEV V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+MCRT_DEV V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+MCRT_DEV V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+MCRT_DEV V3 vdivs(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+// glm::dot(vec3): include/glm/detail/func_geometric.inl:48-55
+MCRT_DEV float dot(V3 a, V3 b)
+{
+    float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z;
+    return tx + ty + tz;
+}
+// glm::cross: func_geometric.inl:68-79
+MCRT_DEV V3 cross(V3 x, V3 y) { return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+// glm::normalize = v * inversesqrt(dot(v,v)): func_geometric.inl:82-90, func_exponential.inl:44-50
+MCRT_DEV V3 normalize(V3 v)
+{
+    float inv = 1.0f / sqrtf(dot(v, v));
+    return v * inv;
+}
+// glm::reflect: func_geometric.inl:104-110
+MCRT_DEV V3 reflect(V3 I, V3 N) { return I - (N * dot(N, I)) * 2.0f; }
+
+MCRT_DEV D3 dmk(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
+MCRT_DEV D3 operator+(D3 a, D3 b) { return dmk(a.x + b.x, a.y + b.y, a.z + b.z); }
+MCRT_DEV D3 operator*(D3 a, D3 b) { return dmk(a.x * b.x, a.y * b.y, a.z * b.z); }
+MCRT_DEV D3 operator*(D3 a, double s) { return dmk(a.x * s, a.y * s, a.z * s); }
+MCRT_DEV D3 ddivs(D3 a, double s) { return dmk(a.x / s, a.y / s, a.z / s); }
+
+// ------------------------------------------------------------- image access
+// P is either an LDS pointer (address_space(3)) or a global pointer.
+typedef const __attribute__((address_space(3))) uint32_t* LdsPtr;
+typedef const uint32_t* GlbPtr;
+
+template <class P> MCRT_DEV float ldf(P p, uint32_t i) { return __uint_as_float(p[i]); }
+template <class P> MCRT_DEV V3 ld3(P p, uint32_t i) { return mk(ldf(p, i), ldf(p, i + 1), ldf(p, i + 2)); }
+template <class P> MCRT_DEV double ldd(P p, uint32_t i)
+{
+    uint64_t u = (uint64_t)p[i] | ((uint64_t)p[i + 1] << 32);
+    return __longlong_as_double((long long)u);
+}
+template <class P> MCRT_DEV D3 ldd3(P p, uint32_t i) { return dmk(ldd(p, i), ldd(p, i + 2), ldd(p, i + 4)); }
+
+// ---------------------------------------------------------------------- rng
+// xorshift128+ and the 52-bit mantissa trick: source/core/randomization.h:23-43;
+// float wrappers source/core/randomization.cpp:25-33.
+struct Rng { uint64_t s0, s1; };
+
+MCRT_DEV uint64_t rng_next(Rng& g)
+{
+    uint64_t x = g.s0;
+    const uint64_t y = g.s1;
+    g.s0 = y;
+    x ^= x << 23;
+    g.s1 = x ^ y ^ (x >> 17) ^ (y >> 26);
+    return g.s1 + y;
+}
+MCRT_DEV double rng_double(Rng& g)
+{
+    uint64_t bits = (0x3FFull << 52) | (rng_next(g) >> 12);
+    return __longlong_as_double((long long)bits) - 1.0;
+}
+MCRT_DEV float rng_float(Rng& g) { return (float)rng_double(g); }
+MCRT_DEV float rng_float01(Rng& g) { return 0.0f + (1.0f - 0.0f) * (float)rng_double(g); }   // RandomFloat(0.0f, 1.0f)
+
+__host__ __device__ inline uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// Counter (seed, pixel, sample) -> generator state; replaces std::random_device seeding
+// (source/core/randomization.cpp:8-13).  mcrt_rng_seed exports the same mapping.
+__host__ __device__ inline void sample_seed(uint64_t seed, uint32_t pixel, uint32_t sample, uint64_t& s0, uint64_t& s1)
+{
+    uint64_t z = seed + (uint64_t)pixel * 0x9E3779B97F4A7C15ull + (uint64_t)sample * 0xD1B54A32D192ED03ull;
+    s0 = mix64(z + 0x9E3779B97F4A7C15ull);
+    s1 = mix64(z + 0x3C6EF372FE94F82Aull);
+    if ((s0 | s1) == 0) s1 = 1;
+}
+
+// ------------------------------------------------------ float trig via double
+// sinf/cosf/tanf/acosf with a fixed operation order (double minimax kernels,
+// one rounding to float).  Within 1 ulp of glibc's, equal on > 99.9 % of
+// inputs; the test oracle carries the same sequences, so device and host
+// agree bit for bit.
+MCRT_DEV double pm_ksin(double x)
+{
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double z = x * x;
+    double p = S5 + z * S6;
+    p = S4 + z * p;
+    p = S3 + z * p;
+    p = S2 + z * p;
+    p = S1 + z * p;
+    return x + (x * z) * p;
+}
+MCRT_DEV double pm_kcos(double x)
+{
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double z = x * x;
+    double p = C5 + z * C6;
+    p = C4 + z * p;
+    p = C3 + z * p;
+    p = C2 + z * p;
+    p = C1 + z * p;
+    return (1.0 - 0.5 * z) + (z * z) * p;
+}
+MCRT_DEV void pm_sincos_d(float xf, double& s, double& c)
+{
+    const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17, TWO_OVER_PI = 6.36619772367581382433e-01;
+    double x = (double)xf;
+    double kd = floor(x * TWO_OVER_PI + 0.5);
+    double r = (x - kd * PIO2_HI) - kd * PIO2_LO;
+    int q = (int)((long long)kd & 3);
+    double sr = pm_ksin(r), cr = pm_kcos(r);
+    if (q == 0) { s = sr; c = cr; }
+    else if (q == 1) { s = cr; c = -sr; }
+    else if (q == 2) { s = -sr; c = -cr; }
+    else { s = -cr; c = sr; }
+}
+MCRT_DEV float pm_nan(float x) { return (x - x) / (x - x); }
+MCRT_DEV float pm_sinf(float x)
+{
+    if (!(fabsf(x) <= 8192.0f)) return pm_nan(x);
+    double s, c; pm_sincos_d(x, s, c); return (float)s;
+}
+MCRT_DEV float pm_cosf(float x)
+{
+    if (!(fabsf(x) <= 8192.0f)) return pm_nan(x);
+    double s, c; pm_sincos_d(x, s, c); return (float)c;
+}
+MCRT_DEV void pm_sincosf(float x, float& sf, float& cf)
+{
+    if (!(fabsf(x) <= 8192.0f)) { sf = cf = pm_nan(x); return; }
+    double s, c; pm_sincos_d(x, s, c); sf = (float)s; cf = (float)c;
+}
+MCRT_DEV float pm_tanf(float x)
+{
+    if (!(fabsf(x) <= 8192.0f)) return pm_nan(x);
+    double s, c; pm_sincos_d(x, s, c); return (float)(s / c);
+}
+MCRT_DEV double pm_asin_r(double z)
+{
+    const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01,
+                 pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
+                 qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
+                 qS4 = 7.70381505559019352791e-02;
+    double p = pS4 + z * pS5;
+    p = pS3 + z * p;
+    p = pS2 + z * p;
+    p = pS1 + z * p;
+    p = pS0 + z * p;
+    p = z * p;
+    double q = qS3 + z * qS4;
+    q = qS2 + z * q;
+    q = qS1 + z * q;
+    q = 1.0 + z * q;
+    return p / q;
+}
+MCRT_DEV float pm_acosf(float xf)
+{
+    const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17, PI = 3.14159265358979311600e+00;
+    double x = (double)xf;
+    if (!(fabs(x) <= 1.0)) return (float)((x - x) / (x - x));
+    if (fabs(x) < 0.5) {
+        double z = x * x;
+        double a = x + x * pm_asin_r(z);
+        return (float)((PIO2_HI - a) + PIO2_LO);
+    }
+    if (x < 0.0) {
+        double z = (1.0 + x) * 0.5;
+        double s = sqrt(z);
+        double a = s + s * pm_asin_r(z);
+        return (float)(PI - 2.0 * a);
+    } else {
+        double z = (1.0 - x) * 0.5;
+        double s = sqrt(z);
+        double a = s + s * pm_asin_r(z);
+        return (float)(2.0 * a);
+    }
+}
+
+// ------------------------------------------------------------- primitives
+// Triangle::Intersects, source/core/triangle.h:25-62 (edges precomputed at upload).
+template <class P> MCRT_DEV bool tri_hit(P big, uint32_t rec, V3 o, V3 d, float& t)
+{
+    V3 v0 = ld3(big, rec + TRI_V0);
+    V3 edge1 = ld3(big, rec + TRI_E1);
+    V3 edge2 = ld3(big, rec + TRI_E2);
+    V3 h = cross(d, edge2);
+    float a = dot(edge1, h);
+    if (fabsf(a) < kFltEpsilon) return false;
+    float f = 1.0f / a;
+    V3 s = o - v0;
+    float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    V3 q = cross(s, edge1);
+    float v = f * dot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = f * dot(edge2, q);
+    return t > kFltEpsilon;
+}
+
+// SphereObject::Intersects, source/objects/sphere.h:16-52
+template <class P> MCRT_DEV bool sphere_hit(P sm, uint32_t orec, V3 o, V3 d, float& t)
+{
+    float radius = ldf(sm, orec + OBJ_RADIUS);
+    if (radius < kFltEpsilon) return false;
+    float radiusSq = radius * radius;
+    V3 L = ld3(sm, orec + OBJ_POS) - o;
+    float tca = dot(L, d);
+    if (tca < 0) return false;
+    float distanceSq = dot(L, L) - tca * tca;
+    if (distanceSq > radiusSq) return false;
+    float thc = sqrtf(radiusSq - distanceSq);
+    float t0 = tca - thc;
+    float t1 = tca + thc;
+    if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
+    if (t0 < 0) {
+        t0 = t1;
+        if (t0 < 0) return false;
+    }
+    t = t0;
+    return true;
+}
+
+// AABB::IntersectsRay, source/core/aabb.h:49-96.  The reference widens the
+// float quotients to double before min/max; widening preserves order, so the
+// comparisons are done on the floats.
+template <class P> MCRT_DEV bool gate_hit(P sm, uint32_t orec, V3 o, V3 d)
+{
+    float tmin = -kFltMax, tmax = kFltMax;
+    const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (dd[a] != 0.0f) {
+            float t1 = (ldf(sm, orec + OBJ_AABB_MIN + a) - oo[a]) / dd[a];
+            float t2 = (ldf(sm, orec + OBJ_AABB_MAX + a) - oo[a]) / dd[a];
+            float lo = (t2 < t1) ? t2 : t1;
+            float hi = (t1 < t2) ? t2 : t1;
+            tmin = (tmin < lo) ? lo : tmin;
+            tmax = (hi < tmax) ? hi : tmax;
+        }
+    }
+    return tmax >= tmin;
+}
+
+struct Counters { uint32_t rays, nodes, tris, spheres, gates; };
+
+struct Hit { uint32_t prim; uint32_t obj; uint32_t elem; float t; };   // obj == MISS on a miss
+
+// (t, prim) beats the current best: strictly nearer, or equally near with a lower primitive id.
+// A fresh `best` has t == FLT_MAX and prim == MISS and is only beaten by t < FLT_MAX, as in the
+// reference's strict `<` against FLOAT_INFINITY.
+MCRT_DEV bool nearer(float t, uint32_t prim, const Hit& best)
+{
+    return t < best.t || (t == best.t && best.prim != MISS && prim < best.prim);
+}
+
+// Scene::IntersectRay restated literally: source/scene.cpp:62-80 with
+// TriangleMesh::Intersects, source/objects/mesh.cpp:9-41.
+template <class PS, class PB, bool kCount>
+MCRT_DEV Hit cast_brute(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters& cn)
+{
+    Hit best; best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax;
+    if (kCount) cn.rays++;
+    for (uint32_t i = 0; i < v.nobj; ++i) {
+        uint32_t orec = v.off_obj + i * OBJ_STRIDE;
+        uint32_t kind = sm[orec + OBJ_KIND];
+        if (kind == MCRT_OBJECT_SPHERE) {
+            float t;
+            if (kCount) cn.spheres++;
+            if (sphere_hit(sm, orec, o, d, t) && t < best.t) { best.obj = i; best.elem = 0; best.t = t; best.prim = sm[orec + OBJ_FIRST_PRIM]; }
+        } else {
+            if (kCount) cn.gates++;
+            if (!gate_hit(sm, orec, o, d)) continue;
+            uint32_t first = sm[orec + OBJ_FIRST_TRI], count = sm[orec + OBJ_TRI_COUNT];
+            uint32_t elementIndex = 0;
+            float nearest = kFltMax, hitDistance = kFltMax;
+            for (uint32_t k = 0; k < count; ++k) {
+                if (kCount) cn.tris++;
+                if (tri_hit(big, v.off_tri + (first + k) * TRI_STRIDE, o, d, hitDistance) && hitDistance < nearest) {
+                    nearest = hitDistance; elementIndex = k;
+                }
+            }
+            if (nearest < kFltMax && nearest < best.t) { best.obj = i; best.elem = elementIndex; best.t = nearest; best.prim = sm[orec + OBJ_FIRST_PRIM] + elementIndex; }
+        }
+    }
+    return best;
+}
+
+// Nearest hit through the flat octree.  Same result as cast_brute: the
+// candidate set is every primitive whose mesh gate passes, the winner is the
+// lexicographic minimum of (t, primitive id) - "earlier object / earlier
+// triangle wins ties", source/scene.cpp:73 and source/objects/mesh.cpp:22.
+// The mesh gate (source/objects/mesh.cpp:11-16) is a pure function of (ray,
+// mesh); it is evaluated the first time the ray meets a triangle of that mesh
+// and cached in two 64-bit masks.
+template <class PS, class PB, bool kCount>
+MCRT_DEV Hit cast_octree(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters& cn)
+{
+    Hit best; best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax;
+    if (kCount) cn.rays++;
+    uint64_t gate_known = 0, gate_pass = 0;
+
+    // Node culling is conservative (boxes are padded at build time), so fast reciprocals are fine here.
+    const float ix = __frcp_rn(d.x), iy = __frcp_rn(d.y), iz = __frcp_rn(d.z);
+    // visit octants front to back: flip the octant index on axes where the ray runs backwards
+    const uint32_t flip = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+    const uint32_t nn = v.nnode;
+
+    uint32_t stack_node[TRAVERSAL_STACK];
+    float stack_t[TRAVERSAL_STACK];
+    int sp = 0;
+    stack_node[sp] = 0; stack_t[sp] = 0.0f; ++sp;
+
+    while (sp > 0) {
+        --sp;
+        const uint32_t node = stack_node[sp];
+        if (stack_t[sp] > best.t) continue;
+        if (kCount) cn.nodes++;
+
+        uint32_t ref = big[v.off_node + NODE_REFS * nn + node];
+        if (ref != NO_REFS) {
+            uint32_t e;
+            do {
+                e = big[v.off_refs + ref++];
+                const uint32_t prim = e & ~REF_LAST;
+                const uint32_t obj = big[v.off_prim_obj + prim];
+                const uint32_t orec = v.off_obj + obj * OBJ_STRIDE;
+                const uint32_t first_prim = sm[orec + OBJ_FIRST_PRIM];
+                float t;
+                bool h;
+                if (sm[orec + OBJ_KIND] == MCRT_OBJECT_SPHERE) {
+                    if (kCount) cn.spheres++;
+                    h = sphere_hit(sm, orec, o, d, t);
+                } else {
+                    // mesh gate, evaluated once per (ray, mesh) on first contact
+                    const uint64_t bit = 1ull << obj;
+                    if (!(gate_known & bit)) {
+                        if (kCount) cn.gates++;
+                        gate_known |= bit;
+                        if (gate_hit(sm, orec, o, d)) gate_pass |= bit;
+                    }
+                    h = false;
+                    if (gate_pass & bit) {
+                        if (kCount) cn.tris++;
+                        h = tri_hit(big, v.off_tri + (sm[orec + OBJ_FIRST_TRI] + (prim - first_prim)) * TRI_STRIDE, o, d, t);
+                    }
+                }
+                if (h && nearer(t, prim, best)) {
+                    best.prim = prim; best.obj = obj; best.elem = prim - first_prim; best.t = t;
+                }
+            } while (!(e & REF_LAST));
+        }
+
+        const uint32_t cw = big[v.off_node + NODE_CHILD * nn + node];
+        const uint32_t mask = cw >> 24;
+        if (mask) {
+            const uint32_t base = cw & 0x00FFFFFFu;
+            // push far octants first so the nearest is popped first
+#pragma unroll 1
+            for (int k = 7; k >= 0; --k) {
+                const uint32_t oct = (uint32_t)k ^ flip;
+                if (!(mask & (1u << oct))) continue;
+                const uint32_t child = base + __popc(mask & ((1u << oct) - 1u));
+                float t0 = 0.0f, t1 = best.t;
+                {
+                    float a = (ldf(big, v.off_node + NODE_MIN_X * nn + child) - o.x) * ix;
+                    float b = (ldf(big, v.off_node + NODE_MAX_X * nn + child) - o.x) * ix;
+                    t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
+                    a = (ldf(big, v.off_node + NODE_MIN_Y * nn + child) - o.y) * iy;
+                    b = (ldf(big, v.off_node + NODE_MAX_Y * nn + child) - o.y) * iy;
+                    t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
+                    a = (ldf(big, v.off_node + NODE_MIN_Z * nn + child) - o.z) * iz;
+                    b = (ldf(big, v.off_node + NODE_MAX_Z * nn + child) - o.z) * iz;
+                    t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
+                }
+                if (t0 <= t1) { stack_node[sp] = child; stack_t[sp] = t0; ++sp; }
+            }
+        }
+    }
+    return best;
+}
+
+template <int kAccel, class PS, class PB, bool kCount>
+MCRT_DEV Hit cast(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters& cn)
+{
+    if (kAccel == MCRT_ACCEL_BRUTE) return cast_brute<PS, PB, kCount>(sm, big, v, o, d, cn);
+    return cast_octree<PS, PB, kCount>(sm, big, v, o, d, cn);
+}
+
+// --------------------------------------------------------------- materials
+// Material::BRDF, source/core/material.h:24-53
+template <class PS> MCRT_DEV double brdf(PS sm, uint32_t orec, V3 incident, V3 reflection, V3 normal)
+{
+    float albedo = ldf(sm, orec + OBJ_ALBEDO);
+    if (sm[orec + OBJ_DIFFUSE] == MCRT_DIFFUSE_OREN_NAYAR) {
+        float roughness = ldf(sm, orec + OBJ_ROUGHNESS);
+        float sigma2 = roughness * roughness;
+        float A = 1.0f - 0.5f * sigma2 / (sigma2 + 0.57f);
+        float B = 0.45f * sigma2 / (sigma2 + 0.09f);
+        float cos_in = dot(incident, normal);
+        float cos_out = dot(reflection, normal);
+        float cos_in_out = dot(incident, reflection);
+        float theta_in = pm_acosf(cos_in);
+        float theta_out = pm_acosf(cos_out);
+        float alpha = (theta_out < theta_in) ? theta_in : theta_out;
+        float beta = (theta_in < theta_out) ? theta_in : theta_out;
+        float mx = (0.0f < cos_in_out) ? cos_in_out : 0.0f;
+        double ON = (double)(A + (B * mx) * pm_sinf(alpha) * pm_tanf(beta));
+        return (double)albedo * ON;
+    }
+    return (double)albedo;
+}
+
+// Scene::RandomHemisphereRay, source/scene.cpp:11-30
+MCRT_DEV V3 hemisphere(V3 Ny, Rng& g, float& cosTheta)
+{
+    V3 Nx, Nz;
+    if (fabsf(Ny.x) > fabsf(Ny.y)) Nx = mk(Ny.z, 0.0f, -Ny.x);
+    else Nx = mk(0.0f, -Ny.z, Ny.y);
+    Nx = normalize(Nx);
+    Nz = normalize(cross(Ny, Nx));
+    cosTheta = rng_float01(g);
+    float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+    float phi = kTwoPiF * rng_float01(g);
+    float sp, cp;
+    pm_sincosf(phi, sp, cp);
+    V3 s = mk(sinTheta * cp, cosTheta, sinTheta * sp);
+    return mk(s.x * Nx.x + s.y * Ny.x + s.z * Nz.x, s.x * Nx.y + s.y * Ny.y + s.z * Nz.y, s.x * Nx.z + s.y * Ny.z + s.z * Nz.z);
+}
+
+// Object::GetRandomPointOnSurface: Light (source/objects/light.h:47-53), SphereObject
+// (source/objects/sphere.h:59-69), base Object (source/objects/object.h:26-29).
+template <class PS> MCRT_DEV V3 light_point(PS sm, uint32_t orec, Rng& g)
+{
+    V3 pos = ld3(sm, orec + OBJ_POS);
+    uint32_t kind = sm[orec + OBJ_KIND];
+    if (kind == MCRT_OBJECT_LIGHT) {
+        float u = rng_float(g);
+        float w = rng_float(g);
+        V3 xv = ld3(sm, orec + OBJ_LIGHT_X), yv = ld3(sm, orec + OBJ_LIGHT_Y);
+        V3 corner = (pos - vdivs(xv, 2.0f)) - vdivs(yv, 2.0f);
+        return (corner + xv * u) + yv * w;
+    }
+    if (kind == MCRT_OBJECT_SPHERE) {
+        float u = rng_float(g);
+        float w = rng_float(g);
+        float radius = ldf(sm, orec + OBJ_RADIUS);
+        float theta = kTwoPiF * u;
+        float phi = pm_acosf(2.0f * w - 1.0f);
+        float sphi, cphi, sth, cth;
+        pm_sincosf(phi, sphi, cphi);
+        pm_sincosf(theta, sth, cth);
+        return mk(pos.x + (radius * sphi * cth), pos.y + (radius * sphi * sth), pos.z + (radius * cphi));
+    }
+    return pos;
+}
+
+// Object::GetSurfaceNormal: sphere.h:54-57 / mesh.cpp:43-46
+template <class PS, class PB> MCRT_DEV V3 surface_normal(PS sm, PB big, const SceneView& v, const Hit& h, V3 p)
+{
+    uint32_t orec = v.off_obj + h.obj * OBJ_STRIDE;
+    if (sm[orec + OBJ_KIND] == MCRT_OBJECT_SPHERE) return normalize(p - ld3(sm, orec + OBJ_POS));
+    return ld3(big, v.off_tri + (sm[orec + OBJ_FIRST_TRI] + h.elem) * TRI_STRIDE + TRI_N);
+}
+
+// Scene::MaxImportance, source/scene.h:45-48 (std::max(a,b) = a<b ? b : a)
+MCRT_DEV double max_importance(D3 i)
+{
+    double yz = (i.y < i.z) ? i.z : i.y;
+    return (i.x < yz) ? yz : i.x;
+}
+
+// Camera::GetPixelRay, source/core/camera.h:36-57
+struct CameraDev {
+    float pos[3];
+    float fov_scale;
+    float view[16];
+    uint32_t width, height;
+    double dx, dy;       // PixelBuffer::deltaX/deltaY, source/core/pixelbuffer.cpp:20-21
+    float aspect_f;      // float(pixels.aspectRatio())
+};
+
+MCRT_DEV void camera_ray(const CameraDev& c, float x, float y, V3& o, V3& d)
+{
+    V3 dir = mk((float)(-1.0f + x * c.dx), (float)(1.0f - y * c.dy), -1.0f);
+    dir.x *= c.fov_scale * c.aspect_f;
+    dir.y *= c.fov_scale;
+    const float* m = c.view;
+    float r[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float add0 = m[0 + k] * dir.x + m[4 + k] * dir.y;
+        float add1 = m[8 + k] * dir.z + m[12 + k] * 0.0f;
+        r[k] = add0 + add1;
+    }
+    o = mk(c.pos[0], c.pos[1], c.pos[2]);
+    d = normalize(mk(r[0], r[1], r[2]));
+}
+
+} // namespace mcrt

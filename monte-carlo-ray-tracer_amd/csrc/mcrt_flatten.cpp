@@ -1,0 +1,334 @@
+// mcrt_flatten.cpp - host half of mcrt_upload_scene.
+//
+// Replaces Scene::PrepareForRayTracing (source/scene.cpp:38-59): the light
+// cache (:41-49) becomes an index list, and Octree::Fill / Subdivide /
+// InsertIfOverlaps (source/accelerationstructures/octree.h:50-92,168-223) are
+// rebuilt as a per-PRIMITIVE octree (the reference's is per object, never
+// queried and non-functional) that is then flattened
+// breadth-first into the SoA arrays of mcrt_layout.h.
+//
+// What is kept from the reference structure: 8-way axis-aligned subdivision
+// at the cell centre, a `maxCount` leaf threshold (octree.h:31), the root box
+// as the union of the member boxes (octree.h:83-86), and the "give up when a
+// split separates nothing" rule (octree.h:195-212).  What differs, so that
+// queries equal the brute force of source/scene.cpp:62-80 exactly:
+//   - members are single triangles / spheres with their TRUE bounds (the
+//     reference boxes spheres at half size, source/objects/sphere.h:71-74);
+//   - a primitive larger than a child cell stays in the interior node's own
+//     list instead of being copied into every child it touches;
+//   - every node stores the padded union of (member box  intersect  cell), so
+//     a float slab test on it can never cull a node holding the nearest hit.
+#include "mcrt_flatten.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+namespace mcrt {
+namespace {
+
+struct Box {
+    float mn[3], mx[3];
+};
+
+inline Box empty_box()
+{
+    Box b;
+    for (int a = 0; a < 3; ++a) { b.mn[a] = FLT_MAX; b.mx[a] = -FLT_MAX; }
+    return b;
+}
+inline void grow(Box& b, const Box& o)
+{
+    for (int a = 0; a < 3; ++a) { b.mn[a] = std::min(b.mn[a], o.mn[a]); b.mx[a] = std::max(b.mx[a], o.mx[a]); }
+}
+inline bool overlaps(const Box& a, const Box& b)
+{
+    for (int k = 0; k < 3; ++k) if (a.mx[k] < b.mn[k] || b.mx[k] < a.mn[k]) return false;
+    return true;
+}
+inline Box clip(const Box& a, const Box& cell)
+{
+    Box r;
+    for (int k = 0; k < 3; ++k) { r.mn[k] = std::max(a.mn[k], cell.mn[k]); r.mx[k] = std::min(a.mx[k], cell.mx[k]); }
+    return r;
+}
+
+struct BuildNode {
+    Box cell;                 // the octant this node owns
+    Box tight;                // union of member boxes clipped to the cell (whole subtree)
+    std::vector<uint32_t> own;  // primitives tested when the node is visited
+    int child[8];             // index into the build-node pool or -1
+    uint32_t depth;
+};
+
+struct Builder {
+    const std::vector<Box>& prim_box;   // padded primitive bounds
+    uint32_t max_leaf, max_depth;
+    std::vector<BuildNode> pool;
+    uint32_t deepest = 0;
+
+    int make(const Box& cell, std::vector<uint32_t>& members, uint32_t depth)
+    {
+        int id = int(pool.size());
+        pool.emplace_back();
+        {
+            BuildNode& n = pool.back();
+            n.cell = cell;
+            n.depth = depth;
+            for (int c = 0; c < 8; ++c) n.child[c] = -1;
+            n.tight = empty_box();
+            for (uint32_t p : members) grow(n.tight, clip(prim_box[p], cell));
+        }
+        deepest = std::max(deepest, depth);
+
+        if (members.size() <= max_leaf || depth >= max_depth) {
+            pool[id].own.swap(members);
+            return id;
+        }
+
+        float half[3], centre[3];
+        for (int a = 0; a < 3; ++a) { half[a] = 0.5f * (cell.mx[a] - cell.mn[a]); centre[a] = cell.mn[a] + half[a]; }
+        const float child_extent = std::max(half[0], std::max(half[1], half[2]));
+
+        // Large primitives stay here; the rest go down.
+        std::vector<uint32_t> own, down;
+        for (uint32_t p : members) {
+            const Box& b = prim_box[p];
+            float ext = std::max(b.mx[0] - b.mn[0], std::max(b.mx[1] - b.mn[1], b.mx[2] - b.mn[2]));
+            (ext > child_extent ? own : down).push_back(p);
+        }
+        members.clear();
+        members.shrink_to_fit();
+
+        if (!down.empty()) {
+            Box cells[8];
+            std::vector<uint32_t> lists[8];
+            for (int c = 0; c < 8; ++c)
+                for (int a = 0; a < 3; ++a) {
+                    bool hi = (c >> a) & 1;
+                    cells[c].mn[a] = hi ? centre[a] : cell.mn[a];
+                    cells[c].mx[a] = hi ? cell.mx[a] : centre[a];
+                }
+            size_t placed = 0;
+            for (uint32_t p : down)
+                for (int c = 0; c < 8; ++c)
+                    if (overlaps(prim_box[p], cells[c])) { lists[c].push_back(p); ++placed; }
+            // The reference's guard (octree.h:195-212): a split that repeats every member in
+            // every child separates nothing.
+            if (placed >= down.size() * 8) {
+                own.insert(own.end(), down.begin(), down.end());
+            } else {
+                down.clear();
+                down.shrink_to_fit();
+                for (int c = 0; c < 8; ++c)
+                    if (!lists[c].empty()) {
+                        int ch = make(cells[c], lists[c], depth + 1);
+                        pool[id].child[c] = ch;
+                    }
+            }
+        }
+        std::sort(own.begin(), own.end());
+        pool[id].own.swap(own);
+        return id;
+    }
+};
+
+inline uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+void put_double(std::vector<uint32_t>& img, size_t at, double v)
+{
+    uint64_t u; std::memcpy(&u, &v, 8);
+    img[at] = uint32_t(u & 0xFFFFFFFFu);
+    img[at + 1] = uint32_t(u >> 32);
+}
+
+bool finite3(const float* v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
+
+} // namespace
+
+int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, FlatScene& out, std::string& err)
+{
+    if (!sc || (sc->object_count && !sc->objects) || (sc->triangle_count && !sc->triangles)) { err = "null scene description"; return MCRT_ERR_INVALID; }
+    if (sc->object_count == 0) { err = "scene has no objects"; return MCRT_ERR_INVALID; }
+    if (sc->object_count > MAX_OBJECTS_GATED) { err = "more than 64 objects: the per-ray mesh-gate cache is a 64-bit mask"; return MCRT_ERR_LIMIT; }
+    if (sc->triangle_count > 0x3FFFFFFFu) { err = "too many triangles"; return MCRT_ERR_LIMIT; }
+
+    const uint32_t nobj = sc->object_count;
+    // ---- validate, number the primitives in (object, element) order ------------------
+    std::vector<uint32_t> first_prim(nobj);
+    std::vector<uint32_t> prim_obj;
+    prim_obj.reserve(size_t(sc->triangle_count) + nobj);
+    std::vector<uint32_t> lights;
+    for (uint32_t i = 0; i < nobj; ++i) {
+        const mcrt_object& o = sc->objects[i];
+        first_prim[i] = uint32_t(prim_obj.size());
+        if (!finite3(o.position)) { err = "object position is not finite"; return MCRT_ERR_INVALID; }
+        if (o.kind == MCRT_OBJECT_SPHERE) {
+            if (!std::isfinite(o.radius)) { err = "sphere radius is not finite"; return MCRT_ERR_INVALID; }
+            prim_obj.push_back(i);
+        } else if (o.kind == MCRT_OBJECT_MESH || o.kind == MCRT_OBJECT_LIGHT) {
+            if (uint64_t(o.first_triangle) + o.triangle_count > sc->triangle_count) { err = "mesh triangle range outside the triangle array"; return MCRT_ERR_INVALID; }
+            if (!finite3(o.aabb_min) || !finite3(o.aabb_max)) { err = "mesh AABB is not finite"; return MCRT_ERR_INVALID; }
+            for (uint32_t t = 0; t < o.triangle_count; ++t) {
+                const mcrt_triangle& tr = sc->triangles[o.first_triangle + t];
+                if (!finite3(tr.v0) || !finite3(tr.v1) || !finite3(tr.v2)) { err = "triangle vertex is not finite"; return MCRT_ERR_INVALID; }
+                prim_obj.push_back(i);
+            }
+        } else { err = "unknown object kind"; return MCRT_ERR_INVALID; }
+        if (o.material.surface < 0 || o.material.surface > 3 || o.material.diffuse < 0 || o.material.diffuse > 1) { err = "material enum out of range"; return MCRT_ERR_INVALID; }
+        // light cache, source/scene.cpp:41-49
+        if (o.material.emission[0] > 0.0 || o.material.emission[1] > 0.0 || o.material.emission[2] > 0.0) lights.push_back(i);
+    }
+    const uint32_t nprim = uint32_t(prim_obj.size());
+
+    // ---- primitive bounds ------------------------------------------------------------
+    std::vector<Box> pbox(nprim);
+    Box root = empty_box();
+    std::vector<uint32_t> members;
+    members.reserve(nprim);
+    for (uint32_t i = 0; i < nobj; ++i) {
+        const mcrt_object& o = sc->objects[i];
+        if (o.kind == MCRT_OBJECT_SPHERE) {
+            Box& b = pbox[first_prim[i]];
+            float r = std::fabs(o.radius);
+            for (int a = 0; a < 3; ++a) { b.mn[a] = o.position[a] - r; b.mx[a] = o.position[a] + r; }
+            // radius < FLT_EPSILON never intersects (source/objects/sphere.h:18): keep it out of the tree
+            if (o.radius >= FLT_EPSILON) { grow(root, b); members.push_back(first_prim[i]); }
+        } else {
+            for (uint32_t t = 0; t < o.triangle_count; ++t) {
+                const mcrt_triangle& tr = sc->triangles[o.first_triangle + t];
+                Box& b = pbox[first_prim[i] + t];
+                for (int a = 0; a < 3; ++a) {
+                    b.mn[a] = std::min(tr.v0[a], std::min(tr.v1[a], tr.v2[a]));
+                    b.mx[a] = std::max(tr.v0[a], std::max(tr.v1[a], tr.v2[a]));
+                }
+                grow(root, b);
+                members.push_back(first_prim[i] + t);
+            }
+        }
+    }
+    if (members.empty()) { for (int a = 0; a < 3; ++a) { root.mn[a] = -1.0f; root.mx[a] = 1.0f; } }
+
+    float extent = std::max(root.mx[0] - root.mn[0], std::max(root.mx[1] - root.mn[1], root.mx[2] - root.mn[2]));
+    float mag = 0.0f;
+    for (int a = 0; a < 3; ++a) mag = std::max(mag, std::max(std::fabs(root.mn[a]), std::fabs(root.mx[a])));
+    float pad_rel = (accel && accel->pad_rel > 0.0f) ? accel->pad_rel : 1.0e-4f;
+    // absolute padding: a fraction of the scene extent, never below a few hundred ulps of the largest coordinate
+    const float pad = std::max(pad_rel * std::max(extent, 1.0e-3f), 256.0f * FLT_EPSILON * mag);
+    for (Box& b : pbox) for (int a = 0; a < 3; ++a) { b.mn[a] -= pad; b.mx[a] += pad; }
+    for (int a = 0; a < 3; ++a) { root.mn[a] -= 2.0f * pad; root.mx[a] += 2.0f * pad; }
+
+    // ---- build -------------------------------------------------------------------------
+    Builder B{ pbox, 0, 0, {}, 0 };
+    B.max_leaf = (accel && accel->max_leaf_prims) ? accel->max_leaf_prims : 4u;
+    B.max_depth = (accel && accel->max_depth) ? std::min(accel->max_depth, MAX_TREE_DEPTH) : 10u;
+    B.pool.reserve(1024);
+    B.make(root, members, 0);
+    if (B.pool.size() >= (1u << 24)) { err = "octree has more than 2^24 nodes"; return MCRT_ERR_LIMIT; }
+
+    // ---- flatten breadth-first: children of a node are contiguous ----------------------
+    const uint32_t nnode = uint32_t(B.pool.size());
+    std::vector<int> order;           // flat index -> build index
+    std::vector<uint32_t> flat_of(nnode, 0);
+    order.reserve(nnode);
+    order.push_back(0);
+    for (size_t head = 0; head < order.size(); ++head) {
+        const BuildNode& n = B.pool[size_t(order[head])];
+        for (int c = 0; c < 8; ++c)
+            if (n.child[c] >= 0) { flat_of[size_t(n.child[c])] = uint32_t(order.size()); order.push_back(n.child[c]); }
+    }
+
+    out.node_box.assign(size_t(nnode) * 6, 0.0f);
+    out.node_words.assign(size_t(nnode) * 2, 0u);
+    out.refs.clear();
+    for (uint32_t f = 0; f < nnode; ++f) {
+        const BuildNode& n = B.pool[size_t(order[f])];
+        Box t = n.tight;
+        if (t.mn[0] > t.mx[0]) t = n.cell;   // empty subtree (only the root of an empty scene)
+        for (int a = 0; a < 3; ++a) { out.node_box[size_t(f) * 6 + a] = t.mn[a]; out.node_box[size_t(f) * 6 + 3 + a] = t.mx[a]; }
+        uint32_t mask = 0, base = 0;
+        bool have = false;
+        for (int c = 0; c < 8; ++c)
+            if (n.child[c] >= 0) { mask |= 1u << c; if (!have) { base = flat_of[size_t(n.child[c])]; have = true; } }
+        out.node_words[size_t(f) * 2] = (mask << 24) | base;
+        if (n.own.empty()) out.node_words[size_t(f) * 2 + 1] = NO_REFS;
+        else {
+            out.node_words[size_t(f) * 2 + 1] = uint32_t(out.refs.size());
+            for (size_t k = 0; k < n.own.size(); ++k) out.refs.push_back(n.own[k] | (k + 1 == n.own.size() ? REF_LAST : 0u));
+        }
+    }
+    out.tree_depth = B.deepest;
+    out.ref_count = uint32_t(out.refs.size());
+
+    // ---- SMALL image -----------------------------------------------------------------
+    SceneView& v = out.view;
+    v = SceneView{};
+    v.nobj = nobj; v.nlights = uint32_t(lights.size()); v.ntri = sc->triangle_count; v.nprim = nprim; v.nnode = nnode;
+    v.off_obj = 0;
+    v.off_lights = v.off_obj + nobj * OBJ_STRIDE;
+    v.off_bg = (v.off_lights + v.nlights + 1u) & ~1u;   // doubles: even word offset
+    v.small_words = v.off_bg + 6;
+    out.small_img.assign(v.small_words, 0u);
+    for (uint32_t i = 0; i < nobj; ++i) {
+        const mcrt_object& o = sc->objects[i];
+        uint32_t* w = out.small_img.data() + v.off_obj + size_t(i) * OBJ_STRIDE;
+        w[OBJ_KIND] = uint32_t(o.kind);
+        w[OBJ_FIRST_TRI] = o.first_triangle;
+        w[OBJ_TRI_COUNT] = o.kind == MCRT_OBJECT_SPHERE ? 0u : o.triangle_count;
+        w[OBJ_FIRST_PRIM] = first_prim[i];
+        w[OBJ_RADIUS] = fbits(o.radius);
+        for (int a = 0; a < 3; ++a) {
+            w[OBJ_POS + a] = fbits(o.position[a]);
+            w[OBJ_AABB_MIN + a] = fbits(o.aabb_min[a]);
+            w[OBJ_AABB_MAX + a] = fbits(o.aabb_max[a]);
+            w[OBJ_LIGHT_X + a] = fbits(o.light_x[a]);
+            w[OBJ_LIGHT_Y + a] = fbits(o.light_y[a]);
+        }
+        w[OBJ_SURFACE] = uint32_t(o.material.surface);
+        w[OBJ_DIFFUSE] = uint32_t(o.material.diffuse);
+        w[OBJ_ALBEDO] = fbits(o.material.albedo);
+        w[OBJ_ROUGHNESS] = fbits(o.material.roughness);
+        w[OBJ_IOR] = fbits(o.material.refractive_index);
+        for (int a = 0; a < 3; ++a) {
+            put_double(out.small_img, v.off_obj + size_t(i) * OBJ_STRIDE + OBJ_COLOR + 2 * a, o.material.color[a]);
+            put_double(out.small_img, v.off_obj + size_t(i) * OBJ_STRIDE + OBJ_EMISSION + 2 * a, o.material.emission[a]);
+        }
+    }
+    for (uint32_t k = 0; k < v.nlights; ++k) out.small_img[v.off_lights + k] = lights[k];
+    for (int a = 0; a < 3; ++a) put_double(out.small_img, v.off_bg + 2 * a, sc->background[a]);
+
+    // ---- BIG image -------------------------------------------------------------------
+    uint64_t off = 0;
+    v.off_node = uint32_t(off);      off += uint64_t(nnode) * NODE_ARRAYS;
+    v.off_refs = uint32_t(off);      off += out.refs.size();
+    v.off_prim_obj = uint32_t(off);  off += nprim;
+    off = (off + 3u) & ~uint64_t(3); // triangle records 16-byte aligned
+    v.off_tri = uint32_t(off);       off += uint64_t(sc->triangle_count) * TRI_STRIDE;
+    if (off >= 0xFFFFFFF0ull) { err = "scene image exceeds 16 GiB of words"; return MCRT_ERR_LIMIT; }
+    v.big_words = uint32_t(off);
+    out.big_img.assign(v.big_words, 0u);
+    for (uint32_t f = 0; f < nnode; ++f) {
+        for (uint32_t k = 0; k < 6; ++k) out.big_img[v.off_node + size_t(k) * nnode + f] = fbits(out.node_box[size_t(f) * 6 + k]);
+        out.big_img[v.off_node + size_t(NODE_CHILD) * nnode + f] = out.node_words[size_t(f) * 2];
+        out.big_img[v.off_node + size_t(NODE_REFS) * nnode + f] = out.node_words[size_t(f) * 2 + 1];
+    }
+    std::copy(out.refs.begin(), out.refs.end(), out.big_img.begin() + v.off_refs);
+    std::copy(prim_obj.begin(), prim_obj.end(), out.big_img.begin() + v.off_prim_obj);
+    for (uint32_t t = 0; t < sc->triangle_count; ++t) {
+        const mcrt_triangle& tr = sc->triangles[t];
+        uint32_t* w = out.big_img.data() + v.off_tri + size_t(t) * TRI_STRIDE;
+        for (int a = 0; a < 3; ++a) {
+            // the two subtractions of source/core/triangle.h:31-32, done once (plain IEEE float subtraction)
+            volatile float e1 = tr.v1[a] - tr.v0[a];
+            volatile float e2 = tr.v2[a] - tr.v0[a];
+            w[TRI_V0 + a] = fbits(tr.v0[a]);
+            w[TRI_E1 + a] = fbits(e1);
+            w[TRI_E2 + a] = fbits(e2);
+            w[TRI_N + a] = fbits(tr.normal[a]);
+        }
+    }
+    return MCRT_OK;
+}
+
+} // namespace mcrt

@@ -1,0 +1,28 @@
+// mcrt_flatten.h - host side of mcrt_upload_scene: scene validation, light
+// cache, per-primitive octree build and packing into the two word images of
+// mcrt_layout.h.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "mcrt.h"
+#include "mcrt_layout.h"
+
+namespace mcrt {
+
+struct FlatScene {
+    std::vector<uint32_t> small_img;
+    std::vector<uint32_t> big_img;
+    SceneView view{};            // pointers left null; filled after upload
+    uint32_t tree_depth = 0;
+    uint32_t ref_count = 0;
+    // kept on the host for mcrt_octree_download
+    std::vector<float> node_box;       // node_count * 6
+    std::vector<uint32_t> node_words;  // node_count * 2
+    std::vector<uint32_t> refs;
+};
+
+// Returns MCRT_OK or an MCRT_ERR_* code with `err` set.
+int flatten_scene(const mcrt_scene_desc* scene, const mcrt_accel_params* accel, FlatScene& out, std::string& err);
+
+} // namespace mcrt

@@ -1,0 +1,72 @@
+// mcrt_layout.h - packed scene image shared by the host flattener and the kernels.
+//
+// Two word-addressed images are built by mcrt_upload_scene:
+//   SMALL: per-object records (geometry header, mesh gate box, light vectors,
+//          material), the light list and the background colour.  A few KB at
+//          most; every kernel stages it in LDS.
+//   BIG:   the flat octree (SoA node arrays + per-node primitive reference
+//          lists), the primitive->object table and the triangle records.
+//          Staged in LDS when SMALL+BIG fit the LDS budget (all Cornell-box
+//          configurations), read from HBM/L2 otherwise (the 1M-triangle mesh).
+//
+// Reference types being flattened: Object/SphereObject/TriangleMesh/Light
+// (source/objects/*.h), Material (source/core/material.h:11-19), Triangle
+// (source/core/triangle.h:8-23), Octree (source/accelerationstructures/octree.h).
+#pragma once
+#include <stdint.h>
+
+namespace mcrt {
+
+// ---- object record (SMALL image), OBJ_STRIDE words each -------------------
+enum : uint32_t {
+    OBJ_KIND = 0,        // MCRT_OBJECT_*
+    OBJ_FIRST_TRI = 1,
+    OBJ_TRI_COUNT = 2,
+    OBJ_FIRST_PRIM = 3,  // id of this object's first primitive (global (object, element) order)
+    OBJ_RADIUS = 4,
+    OBJ_POS = 5,         // 3 floats
+    OBJ_AABB_MIN = 8,    // 3 floats: per-mesh gate, source/objects/mesh.cpp:11-16
+    OBJ_AABB_MAX = 11,
+    OBJ_LIGHT_X = 14,    // Light::xVector
+    OBJ_LIGHT_Y = 17,    // Light::yVector
+    OBJ_SURFACE = 20,
+    OBJ_DIFFUSE = 21,
+    OBJ_ALBEDO = 22,
+    OBJ_ROUGHNESS = 23,
+    OBJ_IOR = 24,
+    OBJ_COLOR = 26,      // 3 doubles (8-byte aligned: stride and offset are even)
+    OBJ_EMISSION = 32,   // 3 doubles
+    OBJ_STRIDE = 40
+};
+
+// ---- triangle record (BIG image), TRI_STRIDE words each, 16-byte aligned --
+// v0, edge1 = v1 - v0, edge2 = v2 - v0 (the two subtractions of
+// source/core/triangle.h:31-32 done once at upload: same floats), face normal.
+enum : uint32_t { TRI_V0 = 0, TRI_E1 = 3, TRI_E2 = 6, TRI_N = 9, TRI_STRIDE = 12 };
+
+// ---- octree node arrays (BIG image), SoA: array k lives at off_node + k*node_count
+enum : uint32_t {
+    NODE_MIN_X = 0, NODE_MIN_Y = 1, NODE_MIN_Z = 2, NODE_MAX_X = 3, NODE_MAX_Y = 4, NODE_MAX_Z = 5,
+    NODE_CHILD = 6,      // bits 0..23: index of the first child (children are contiguous,
+                         // only non-empty octants are stored), bits 24..31: octant mask
+    NODE_REFS = 7,       // index of this node's first primitive reference, NO_REFS if none
+    NODE_ARRAYS = 8
+};
+constexpr uint32_t NO_REFS = 0xFFFFFFFFu;
+constexpr uint32_t REF_LAST = 0x80000000u;   // set on the last reference of a node's list
+constexpr uint32_t MISS = 0xFFFFFFFFu;
+
+constexpr uint32_t MAX_TREE_DEPTH = 12;
+constexpr uint32_t TRAVERSAL_STACK = 7 * MAX_TREE_DEPTH + 4;
+constexpr uint32_t MAX_OBJECTS_GATED = 64;   // mesh-gate cache is a 64-bit mask per ray
+
+struct SceneView {
+    const uint32_t* small_img;   // global copies of the two images
+    const uint32_t* big_img;
+    uint32_t small_words, big_words;
+    uint32_t nobj, nlights, ntri, nprim, nnode;
+    uint32_t off_obj, off_lights, off_bg;            // into SMALL
+    uint32_t off_node, off_refs, off_prim_obj, off_tri;  // into BIG
+};
+
+} // namespace mcrt

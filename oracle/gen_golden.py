@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE: regenerate tests/golden/*.npz from the REFERENCE ITSELF.
+
+Runs the reference's own translation units (oracle/_ref/libmcrt_ref.so, built
+by oracle/Makefile from /root/reference) on seeded inputs and stores inputs +
+outputs as small .npz fixtures.  Only data is stored - no reference source.
+The reference ships no tests, golden vectors or seed control, so
+these fixtures are what pins oracle/mcrt_oracle.c (tests/test_oracle_golden.py)
+and, through it, the HIP kernels.
+
+Usage:  make -C oracle ref && python oracle/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import pyoracle as po  # noqa: E402
+import mcrt_pkg  # noqa: E402
+
+pkg = mcrt_pkg.load()
+from mcrt_amd import abi, scenes  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+SEED = 0x5EED0001
+DEPTH = 100
+F = np.float32
+
+
+def unit(v):
+    v = np.asarray(v, F)
+    n = np.sqrt((v * v).sum(axis=1, dtype=F), dtype=F)
+    n[n == 0] = 1
+    return (v / n[:, None]).astype(F)
+
+
+def make_rays(R, scene, cam, flat, rng, n_random=6000, n_secondary=6000):
+    """Primary grid + harvested secondary rays + random + adversarial rays."""
+    os_, ds_ = [], []
+    # (a) primary 64x64 grid through pixel centres
+    g = (np.arange(64, dtype=F) * F(cam.width / 64.0) + F(0.5))
+    xs, ys = np.meshgrid(g, g)
+    po_, pd_ = R.camera_rays(cam, xs.ravel(), ys.ravel())
+    os_.append(po_); ds_.append(pd_)
+    # (b) secondary rays: leave the primary hit points in random directions
+    obj, elem, t = R.intersect(scene, po_, pd_)
+    hit = obj >= 0
+    p = (po_[hit] + pd_[hit] * t[hit, None]).astype(F)
+    nrm = R.surface_normal(scene, obj[hit], elem[hit], p)
+    idx = rng.integers(0, len(p), n_secondary)
+    dirs = unit(rng.normal(size=(n_secondary, 3)))
+    flip = (dirs * nrm[idx]).sum(axis=1) < 0
+    dirs[flip] *= -1
+    os_.append((p[idx] + nrm[idx] * F(1.1920929e-07 * 20.0)).astype(F)); ds_.append(dirs)
+    # (c) random interior origins and directions
+    o = rng.uniform(-4.9, 4.9, size=(n_random, 3)).astype(F)
+    os_.append(o); ds_.append(unit(rng.normal(size=(n_random, 3))))
+    # (d) adversarial
+    axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], F)
+    o = rng.uniform(-4.9, 4.9, size=(1200, 3)).astype(F)
+    os_.append(o); ds_.append(axes[rng.integers(0, 6, 1200)])
+    # one zero component
+    d = unit(rng.normal(size=(1200, 3)))
+    d[np.arange(1200), rng.integers(0, 3, 1200)] = 0
+    os_.append(rng.uniform(-4.9, 4.9, size=(1200, 3)).astype(F)); ds_.append(unit(d))
+    # aimed exactly at triangle vertices and edge midpoints
+    verts = np.concatenate([flat.triangles["v0"], flat.triangles["v1"], flat.triangles["v2"]])
+    mids = ((flat.triangles["v0"] + flat.triangles["v1"]) * F(0.5)).astype(F)
+    targets = np.concatenate([verts, mids, ((flat.triangles["v1"] + flat.triangles["v2"]) * F(0.5)).astype(F)])
+    for _ in range(6):
+        o = rng.uniform(-4.5, 4.5, size=(len(targets), 3)).astype(F)
+        os_.append(o); ds_.append(unit(targets - o))
+    # origins exactly on the walls / floor, directions inside the plane and slightly off it
+    for axis, val in ((1, -5.0), (1, 5.0), (0, 5.0), (0, -5.0), (2, -5.0)):
+        o = rng.uniform(-4.9, 4.9, size=(300, 3)).astype(F)
+        o[:, axis] = val
+        d = unit(rng.normal(size=(300, 3)))
+        d[:150, axis] = 0
+        d[150:, axis] *= F(1e-4)
+        os_.append(o); ds_.append(unit(d))
+    # grazing the light quad (y = 4.999) and the flat light AABB
+    o = rng.uniform(-4.5, 4.5, size=(600, 3)).astype(F)
+    o[:, 1] = rng.choice(np.array([4.999, 4.9989977, 4.998, 4.9995], F), 600)
+    d = unit(rng.normal(size=(600, 3)))
+    d[:300, 1] = 0
+    os_.append(o); ds_.append(unit(d))
+    # spheres: origins inside, on the surface, tangent rays
+    sph = flat.objects[flat.objects["kind"] == abi.OBJECT_SPHERE]
+    for s in sph:
+        c, r = s["position"], s["radius"]
+        if r <= 0:
+            continue
+        o = (c + unit(rng.normal(size=(200, 3))) * F(r) * rng.uniform(0, 1, size=(200, 1)).astype(F)).astype(F)
+        os_.append(o); ds_.append(unit(rng.normal(size=(200, 3))))
+        o = rng.uniform(-4.5, 4.5, size=(200, 3)).astype(F)
+        tgt = (c + unit(rng.normal(size=(200, 3))) * F(r)).astype(F)       # points on the silhouette sphere
+        os_.append(o); ds_.append(unit(tgt - o))
+    o = np.concatenate(os_).astype(F)
+    d = np.concatenate(ds_).astype(F)
+    return np.ascontiguousarray(o), np.ascontiguousarray(d)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print(f"  {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def scene_fixture(R, name, scene, flat, lights):
+    save(f"scene_{name}.npz", objects=flat.objects.view(np.uint8), triangles=flat.triangles.view(np.uint8),
+         background=np.asarray(flat.background, np.float64), lights=lights)
+
+
+def hits_and_samples(R, name, scene, flat, cam, rng, n_samples):
+    o, d = make_rays(R, scene, cam, flat, rng)
+    obj, elem, t = R.intersect(scene, o, d)
+    save(f"hits_{name}.npz", origins=o, dirs=d, obj=obj, elem=elem, t=t)
+    npix = cam.width * cam.height
+    px = rng.integers(0, npix, n_samples).astype(np.uint32)
+    sm = rng.integers(0, 4096, n_samples).astype(np.uint32)
+    rad = R.trace_samples(scene, cam, px, sm, SEED, DEPTH)
+    save(f"samples_{name}.npz", pixels=px, samples=sm, radiance=rad, seed=np.uint64(SEED), depth=np.uint32(DEPTH),
+         camera=abi.camera_to_numpy(cam))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    if not po.Ref.available():
+        po.build(ref=True)
+    R = po.Ref()
+    rng = np.random.default_rng(20181211)
+
+    print("F1 rng")
+    save("rng.npz", seed=np.array([1, 2], np.uint64), doubles=R.rng_doubles(1, 2, 64), floats=R.rng_floats(1, 2, 64),
+         floats_range=R.rng_floats_range(1, 2, -2.5, 7.25, 64),
+         seed_big=np.array([0x0123456789ABCDEF, 0xFEDCBA9876543210], np.uint64),
+         doubles_big=R.rng_doubles(0x0123456789ABCDEF, 0xFEDCBA9876543210, 64))
+
+    print("F2 cameras")
+    cams = {}
+    for tag, (w, h, fov, pos, tgt) in {
+        "512": (512, 512, 90.0, (0, 0, 5), (0, 0, 0)),
+        "4k": (3840, 2160, 90.0, (0, 0, 5), (0, 0, 0)),
+        "640x480": (640, 480, 90.0, (0, 0, 5), (0, 0, 0)),
+        "oblique": (320, 200, 60.0, (1.5, -2.0, 4.0), (-0.5, 0.25, -1.0)),
+        "hexagon": (256, 256, 90.0, (0, 0, 0), (0, 0, 10)),
+    }.items():
+        cam = R.camera(w, h, fov, pos, tgt)
+        xs = np.concatenate([rng.uniform(0, w, 500), [0.0, 0.5, w - 0.5, w, w / 2]]).astype(F)
+        ys = np.concatenate([rng.uniform(0, h, 500), [0.0, 0.5, h - 0.5, h, h / 2]]).astype(F)
+        o, d = R.camera_rays(cam, xs, ys)
+        cams[tag] = cam
+        save(f"camera_{tag}.npz", camera=abi.camera_to_numpy(cam), args=np.array([w, h, fov, *pos, *tgt, 0, 1, 0], np.float64), xs=xs, ys=ys,
+             origins=o, dirs=d)
+
+    print("F3 scenes + F4 hits + F5 samples")
+    cam512 = cams["512"]
+    cornell = R.cornell()
+    flat, lights = R.dump(cornell)
+    scene_fixture(R, "cornell", cornell, flat, lights)
+    hits_and_samples(R, "cornell", cornell, flat, cam512, rng, 4096)
+
+    point = R.cornell(point=True)
+    pflat, plights = R.dump(point)
+    scene_fixture(R, "cornell_point", point, pflat, plights)
+    hits_and_samples(R, "cornell_point", point, pflat, cam512, rng, 1024)
+
+    hexa = R.hexagon()
+    hflat, hlights = R.dump(hexa)
+    scene_fixture(R, "hexagon", hexa, hflat, hlights)
+    hits_and_samples(R, "hexagon", hexa, hflat, cams["hexagon"], rng, 1024)
+
+    for name, builder in (("config2", scenes.config2), ("config3", scenes.config3)):
+        f = builder(flat)
+        sc = R.scene(f)
+        # what the reference's own ctor / UpdateAABB make of the same vertices (normals, AABBs) is the fixture
+        f2, l2 = R.dump(sc)
+        scene_fixture(R, name, sc, f2, l2)
+        hits_and_samples(R, name, sc, f2, cam512, rng, 2048)
+
+    f4 = scenes.config4(flat, n=2000, seed=42)
+    sc4 = R.scene(f4, reference_octree=False)   # the reference's own (unused) octree build overflows the stack here
+    f4d, l4 = R.dump(sc4)
+    scene_fixture(R, "config4_2k", sc4, f4d, l4)
+    hits_and_samples(R, "config4_2k", sc4, f4d, cam512, rng, 1024)
+
+    print("F6 images (accumulator sums)")
+    cam128 = R.camera(128, 128, 90.0, (0, 0, 5), (0, 0, 0))
+    sums, dropped = R.render(cornell, cam128, 0, 64, DEPTH, SEED, threads=8)
+    save("image_cornell_128_64spp.npz", sums=sums, dropped=np.uint64(dropped), seed=np.uint64(SEED), depth=np.uint32(DEPTH), spp=np.uint32(64),
+         camera=abi.camera_to_numpy(cam128))
+    cam64 = R.camera(64, 64, 90.0, (0, 0, 5), (0, 0, 0))
+    sums, dropped = R.render(cornell, cam64, 0, 1024, DEPTH, SEED, threads=8)
+    sums_b, _ = R.render(cornell, cam64, 0, 1024, DEPTH, SEED + 1, threads=8)
+    save("image_cornell_64_1024spp.npz", sums=sums, sums_other_seed=sums_b, dropped=np.uint64(dropped), seed=np.uint64(SEED), depth=np.uint32(DEPTH),
+         spp=np.uint32(1024), camera=abi.camera_to_numpy(cam64))
+    save("unlit_cornell_128.npz", color=R.render_unlit(cornell, cam128), camera=abi.camera_to_numpy(cam128))
+
+    print("F7 BRDF / hemisphere / normals")
+    n = 4000
+    nrm = unit(rng.normal(size=(n, 3)))
+    inc = unit(rng.normal(size=(n, 3)))
+    inc[(inc * nrm).sum(axis=1) > 0] *= -1                      # incident points into the surface
+    refl = unit(rng.normal(size=(n, 3)))
+    refl[(refl * nrm).sum(axis=1) < 0] *= -1
+    # the exact edge that makes acos return NaN in the reference: |cos| a hair above 1
+    inc[:8] = -nrm[:8] * F(1.0000001)
+    refl[8:16] = nrm[8:16] * F(1.0000002)                      # cos_out > 1 -> theta_out = NaN -> NaN BRDF
+    mats = {}
+    for tag, rough in (("on_05", 0.5), ("on_10", 1.0), ("on_02", 0.2)):
+        m = abi.Material()
+        m.color[:] = (1, 1, 1); m.diffuse = abi.DIFFUSE_OREN_NAYAR; m.albedo = 1.0; m.roughness = rough; m.refractive_index = 1.52
+        mats[tag] = R.brdf(m, inc, refl, nrm)
+    states = rng.integers(1, 2 ** 63, size=(n, 2)).astype(np.uint64)
+    hd, hc = R.hemisphere(nrm, states)
+    # axis-aligned normals too (the |n.x| > |n.y| branch)
+    axn = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], F)[rng.integers(0, 6, 600)]
+    hd2, hc2 = R.hemisphere(axn, states[:600])
+    save("brdf_hemisphere.npz", normals=nrm, incident=inc, reflection=refl, brdf_on_05=mats["on_05"], brdf_on_10=mats["on_10"],
+         brdf_on_02=mats["on_02"], states=states, hemi_dir=hd, hemi_cos=hc, axis_normals=axn, hemi_dir_axis=hd2, hemi_cos_axis=hc2)
+
+    print("F8 tonemap")
+    vals = np.concatenate([rng.uniform(0, 3, 3000), rng.uniform(0, 200, 1500), rng.uniform(-2, 0, 300), [0.0, 1.0, 64.0, 1e-9, 1e6, -1e-9]])
+    vals = np.resize(vals, (len(vals) // 3) * 3).reshape(-1, 3)
+    sums = vals * 64.0
+    rein, mean = R.resolve(sums, 64, abi.TONEMAP_REINHARD)
+    expo, _ = R.resolve(sums, 64, abi.TONEMAP_EXPOSURE, exposure=1.0)
+    expo2, _ = R.resolve(sums, 64, abi.TONEMAP_EXPOSURE, gamma=1.8, exposure=0.35)
+    none, _ = R.resolve(sums, 64, abi.TONEMAP_NONE)
+    save("tonemap.npz", sums=sums, spp=np.uint32(64), mean=mean, reinhard=rein, exposure=expo, exposure_g18_e035=expo2, none=none)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

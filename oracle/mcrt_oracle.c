@@ -905,6 +905,100 @@ ORC_EXPORT void orc_resolve(uint64_t npix, const double* sums, uint64_t spp, int
     }
 }
 
+/* ------------------------------------------------------- flat-octree replay
+ * CPU replay of the product's flat octree traversal (cast_octree in
+ * monte-carlo-ray-tracer_amd/csrc/mcrt_device.h; layout in csrc/mcrt_layout.h)
+ * with visit counters.  The structure itself is product data (downloaded with
+ * mcrt_scene_image_octree / mcrt_octree_download); the leaf tests are this
+ * file's restatements, so `replay == orc_intersect` proves the structure can
+ * never hide the nearest hit, and the counters define the algorithmic bytes of
+ * SURVEY.md 8(d). */
+typedef struct orc_octree {
+    uint32_t node_count;
+    const float* box;        /* node_count * 6: min xyz, max xyz (padded)            */
+    const uint32_t* words;   /* node_count * 2: child word (mask<<24 | first child), first prim ref */
+    const uint32_t* refs;    /* primitive ids, bit 31 = last of the node's list      */
+} orc_octree;
+
+typedef struct orc_octree_stats { uint64_t rays, nodes, tris, spheres, gates; } orc_octree_stats;
+
+ORC_EXPORT int orc_intersect_octree(const orc_scene* S, const orc_octree* T, uint64_t n, const float* o, const float* d,
+                                    int32_t* out_obj, uint32_t* out_elem, float* out_t, orc_octree_stats* st)
+{
+    /* primitive ids are assigned in (object, element) order */
+    uint32_t nprim = 0;
+    uint32_t* first_prim = (uint32_t*)malloc(sizeof(uint32_t) * (S->nobj + 1));
+    for (uint32_t i = 0; i < S->nobj; ++i) { first_prim[i] = nprim; nprim += (S->obj[i].kind == MCRT_OBJECT_SPHERE) ? 1u : S->obj[i].triangle_count; }
+    first_prim[S->nobj] = nprim;
+    uint32_t* prim_obj = (uint32_t*)malloc(sizeof(uint32_t) * (nprim ? nprim : 1));
+    for (uint32_t i = 0; i < S->nobj; ++i) for (uint32_t p = first_prim[i]; p < first_prim[i + 1]; ++p) prim_obj[p] = i;
+    int overflow = 0;
+    enum { STACK = 128 };
+    for (uint64_t i = 0; i < n; ++i) {
+        v3 ro = ld3(o + 3 * i), rd = ld3(d + 3 * i);
+        uint64_t gate_known = 0, gate_pass = 0;
+        const float inv[3] = { 1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z };
+        const float oo[3] = { ro.x, ro.y, ro.z };
+        const uint32_t flip = (rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u);
+        hit_t best = { -1, 0, FLT_MAX };
+        uint32_t bestPrim = 0xFFFFFFFFu;
+        uint32_t stack_node[STACK]; float stack_t[STACK];
+        int sp = 0;
+        stack_node[sp] = 0; stack_t[sp] = 0.0f; ++sp;
+        if (st) st->rays++;
+        while (sp > 0) {
+            --sp;
+            uint32_t node = stack_node[sp];
+            if (stack_t[sp] > best.t) continue;
+            if (st) st->nodes++;
+            uint32_t ref = T->words[2 * (size_t)node + 1];
+            if (ref != 0xFFFFFFFFu) {
+                uint32_t e;
+                do {
+                    e = T->refs[ref++];
+                    uint32_t prim = e & 0x7FFFFFFFu;
+                    uint32_t ob = prim_obj[prim], el = prim - first_prim[ob];
+                    const mcrt_object* O = &S->obj[ob];
+                    float t = 0.0f; int h;
+                    int better;
+                    if (O->kind == MCRT_OBJECT_SPHERE) { if (st) st->spheres++; h = sphere_hit(O, ro, rd, &t); }
+                    else {
+                        uint64_t bit = 1ull << ob;
+                        if (!(gate_known & bit)) {
+                            if (st) st->gates++;
+                            gate_known |= bit;
+                            if (aabb_hit(O->aabb_min, O->aabb_max, ro, rd)) gate_pass |= bit;
+                        }
+                        h = 0;
+                        if (gate_pass & bit) { if (st) st->tris++; h = tri_hit(&S->tri[O->first_triangle + el], ro, rd, &t); }
+                    }
+                    better = h && (t < best.t || (t == best.t && bestPrim != 0xFFFFFFFFu && prim < bestPrim));
+                    if (better) { best.obj = (int32_t)ob; best.elem = el; best.t = t; bestPrim = prim; }
+                } while (!(e & 0x80000000u));
+            }
+            uint32_t cw = T->words[2 * (size_t)node];
+            uint32_t base = cw & 0x00FFFFFFu, mask = cw >> 24;
+            if (mask) {
+                for (int k = 7; k >= 0; --k) {
+                    uint32_t oct = (uint32_t)k ^ flip;
+                    if (!(mask & (1u << oct))) continue;
+                    uint32_t child = base + (uint32_t)__builtin_popcount(mask & ((1u << oct) - 1u));
+                    const float* b = T->box + 6 * (size_t)child;
+                    float t0 = 0.0f, t1 = best.t;
+                    for (int a = 0; a < 3; ++a) {
+                        float x = (b[a] - oo[a]) * inv[a], y = (b[3 + a] - oo[a]) * inv[a];
+                        t0 = fmaxf(t0, fminf(x, y)); t1 = fminf(t1, fmaxf(x, y));
+                    }
+                    if (t0 <= t1) { if (sp < STACK) { stack_node[sp] = child; stack_t[sp] = t0; ++sp; } else overflow = 1; }
+                }
+            }
+        }
+        out_obj[i] = best.obj; out_elem[i] = best.elem; out_t[i] = best.t;
+    }
+    free(first_prim); free(prim_obj);
+    return overflow;
+}
+
 ORC_EXPORT uint32_t orc_abi_sizes(uint32_t out[4])
 {
     out[0] = (uint32_t)sizeof(mcrt_material); out[1] = (uint32_t)sizeof(mcrt_triangle);

@@ -9,7 +9,6 @@ Both expose the same method names so tests can run one against the other.
 Nothing in the product imports this module.
 """
 import ctypes as C
-import importlib.util
 import os
 import subprocess
 import sys
@@ -21,14 +20,11 @@ ROOT = os.path.dirname(HERE)
 
 
 def _load_abi():
-    name = "mcrt_amd_abi"
-    if name in sys.modules:
-        return sys.modules[name]
-    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "monte-carlo-ray-tracer_amd", "abi.py"))
-    mod = importlib.util.module_from_spec(spec)
-    sys.modules[name] = mod
-    spec.loader.exec_module(mod)
-    return mod
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import mcrt_pkg
+
+    return mcrt_pkg.load().abi
 
 
 abi = _load_abi()
@@ -56,6 +52,17 @@ class Stats(C.Structure):
             "max_depth_used", "nonfinite",
         )
     ]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class OctreeView(C.Structure):
+    _fields_ = [("node_count", C.c_uint32), ("box", C.POINTER(C.c_float)), ("words", C.POINTER(C.c_uint32)), ("refs", C.POINTER(C.c_uint32))]
+
+
+class OctreeStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "nodes", "tris", "spheres", "gates")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -179,6 +186,21 @@ class Oracle:
         )
         return obj, elem, t
 
+    def intersect_octree(self, scene, node_box, node_words, prim_refs, origins, dirs, stats=None):
+        """Replay the product's flat octree on the CPU (leaf tests are the oracle's)."""
+        o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)
+        box, words, refs = _f32(node_box), _u32(node_words), _u32(prim_refs)
+        tree = OctreeView(len(box.reshape(-1, 6)), _p(box, C.c_float), _p(words, C.c_uint32), _p(refs, C.c_uint32))
+        n = len(o)
+        obj = np.zeros(n, np.int32); elem = np.zeros(n, np.uint32); t = np.zeros(n, np.float32)
+        self.lib.orc_intersect_octree.restype = C.c_int
+        overflow = self.lib.orc_intersect_octree(
+            C.c_void_p(scene.h), C.byref(tree), C.c_uint64(n), _p(o, C.c_float), _p(d, C.c_float), _p(obj, C.c_int32), _p(elem, C.c_uint32),
+            _p(t, C.c_float), C.byref(stats) if stats is not None else None,
+        )
+        assert overflow == 0, "traversal stack overflow in the replay"
+        return obj, elem, t
+
     def brdf(self, material, incident, reflection, normal, portable_math=False):
         i, r, n = _f32(incident).reshape(-1, 3), _f32(reflection).reshape(-1, 3), _f32(normal).reshape(-1, 3)
         out = np.zeros(len(i), np.float64)
@@ -290,9 +312,9 @@ class Ref:
         h = self.lib.ref_scene_create_hexagon(C.c_float(radius), C.c_double(light), C.c_int(int(point)))
         return _Handle(h, self.lib.ref_scene_destroy)
 
-    def scene(self, flat):
+    def scene(self, flat, reference_octree=True):
         d = flat.desc()
-        h = self.lib.ref_scene_create_from_desc(C.byref(d))
+        h = self.lib.ref_scene_create_from_desc(C.byref(d), C.c_int(int(reference_octree)))
         return _Handle(h, self.lib.ref_scene_destroy, keep=flat)
 
     def dump(self, scene):

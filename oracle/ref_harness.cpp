@@ -126,8 +126,14 @@ void* ref_scene_create_hexagon(float sphere_radius, double light_strength, int u
 }
 
 /* Rebuild a scene from the flat description through the reference's own
- * classes (Scene::CreateObject, Triangle ctor, PrepareForRayTracing). */
-void* ref_scene_create_from_desc(const mcrt_scene_desc* d)
+ * classes (Scene::CreateObject, Triangle ctor, PrepareForRayTracing).
+ * build_reference_octree == 0 skips Octree::Fill: the reference's octree is
+ * never queried (source/scene.cpp:64) and its recursive build
+ * (source/accelerationstructures/octree.h:50-70,168-223) overflows the stack
+ * on some scenes (e.g. a 2000-triangle mesh object among the walls); the
+ * other two steps of PrepareForRayTracing (light cache, UpdateAABB,
+ * source/scene.cpp:41-55) are then run here through the same public members. */
+void* ref_scene_create_from_desc(const mcrt_scene_desc* d, int build_reference_octree)
 {
     Scene* s = new Scene();
     s->backgroundColor = ColorDbl(d->background[0], d->background[1], d->background[2]);
@@ -158,7 +164,16 @@ void* ref_scene_create_from_desc(const mcrt_scene_desc* d)
             }
         }
     }
-    s->PrepareForRayTracing();
+    if (build_reference_octree) s->PrepareForRayTracing();
+    else {
+        std::vector<Object*>& lights = SceneAccess::Lights(*s);
+        lights.clear();
+        for (Object* o : SceneAccess::Objects(*s)) {
+            Material& m = o->material;
+            if (m.emission.r > 0.0 || m.emission.g > 0.0 || m.emission.b > 0.0) lights.push_back(o);
+        }
+        for (Object* o : SceneAccess::Objects(*s)) o->UpdateAABB();
+    }
     RefScene* h = new RefScene;
     h->scene = s;
     return h;

@@ -1,0 +1,128 @@
+"""The CPU restatement (oracle/mcrt_oracle.c) against fixtures produced by the
+reference's own code (oracle/gen_golden.py).  Everything here is bit-exact:
+the oracle uses libm like the reference build and the reference's recursion
+order."""
+import numpy as np
+import pytest
+
+from conftest import SCENES
+
+
+def test_rng_known_answers(oracle, golden):
+    g = golden("rng.npz")
+    s0, s1 = (int(x) for x in g["seed"])
+    assert np.array_equal(oracle.rng_doubles(s0, s1, 64), g["doubles"])
+    assert np.array_equal(oracle.rng_floats(s0, s1, 64), g["floats"])
+    assert np.array_equal(oracle.rng_floats_range(s0, s1, -2.5, 7.25, 64), g["floats_range"])
+    b0, b1 = (int(x) for x in g["seed_big"])
+    assert np.array_equal(oracle.rng_doubles(b0, b1, 64), g["doubles_big"])
+    # SURVEY.md 2.2 probe: seed {1,2} -> 0x1p-41, 0x1p-39, ...
+    assert [float(x).hex() for x in g["doubles"][:2]] == ["0x1.0000000000000p-41", "0x1.0000000000000p-39"]
+
+
+@pytest.mark.parametrize("tag", ["512", "4k", "640x480", "oblique", "hexagon"])
+def test_camera_matrix_and_rays(oracle, golden, pkg, tag):
+    g = golden(f"camera_{tag}.npz")
+    a = g["args"]
+    cam = oracle.camera(int(a[0]), int(a[1]), float(a[2]), a[3:6], a[6:9], a[9:12])
+    assert bytes(cam) == g["camera"].tobytes()
+    o, d = oracle.camera_rays(cam, g["xs"], g["ys"])
+    assert np.array_equal(o, g["origins"])
+    assert np.array_equal(d.view(np.uint32), g["dirs"].view(np.uint32))
+
+
+def test_survey_anchor_rays(oracle, scene_of, golden):
+    """Known-answer anchors of SURVEY.md 8(c)."""
+    cam = oracle.camera(512, 512, 90.0, (0, 0, 5), (0, 0, 0))
+    xs = [0.5, 256.5, 100.25, 400.5, 256.5, 256.5, 180.5, 256.5]
+    ys = [0.5, 256.5, 300.75, 128.5, 40.5, 2.5, 256.5, 330.5]
+    o, d = oracle.camera_rays(cam, xs, ys)
+    assert float(d[0, 0]).hex() == "-0x1.2769180000000p-1"
+    obj, elem, t = oracle.intersect(oracle.scene(scene_of("cornell")), o, d)
+    assert obj.tolist() == [1, 2, 3, 0, 2, 10, 3, 6]
+    assert elem.tolist() == [1, 2, 0, 0, 0, 0, 0, 0]
+    assert [float(x).hex() for x in t[:3]] == ["0x1.154f1a0000000p+3", "0x1.4000500000000p+3", "0x1.a9a1b60000000p+2"]
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_scene_derived_data(oracle, scene_of, golden, name):
+    """Triangle normals, mesh AABBs and the light cache as the reference derives them."""
+    flat = scene_of(name)
+    g = golden(f"scene_{name}.npz")
+    assert np.array_equal(oracle.scene_lights(oracle.scene(flat)), g["lights"])
+    for o in flat.objects:
+        if o["kind"] == 0:
+            continue
+        tris = flat.triangles[o["first_triangle"]:o["first_triangle"] + o["triangle_count"]]
+        mn, mx = oracle.mesh_aabb(o["position"], tris)
+        assert np.array_equal(mn, o["aabb_min"]) and np.array_equal(mx, o["aabb_max"])
+        for t in tris[:64]:
+            n = oracle.triangle_normal(t["v0"], t["v1"], t["v2"])
+            assert np.array_equal(n.view(np.uint32), t["normal"].view(np.uint32)) or (np.isnan(n).all() and np.isnan(t["normal"]).all())
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_intersect_bit_exact(oracle, scene_of, golden, name):
+    g = golden(f"hits_{name}.npz")
+    obj, elem, t = oracle.intersect(oracle.scene(scene_of(name)), g["origins"], g["dirs"])
+    assert np.array_equal(obj, g["obj"])
+    assert np.array_equal(elem, g["elem"])
+    assert np.array_equal(t.view(np.uint32), g["t"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_per_sample_radiance_bit_exact(oracle, pkg, scene_of, golden, name):
+    """F5: pins TraceRay's arithmetic AND its random-draw order (refract branch first)."""
+    g = golden(f"samples_{name}.npz")
+    cam = pkg.abi.camera_from_numpy(g["camera"])
+    rad = oracle.trace_samples(oracle.scene(scene_of(name)), cam, g["pixels"], g["samples"], int(g["seed"]), int(g["depth"]))
+    assert np.array_equal(rad.view(np.uint64), g["radiance"].view(np.uint64))
+
+
+def test_images_bit_exact(oracle, pkg, scene_of, golden):
+    sc = oracle.scene(scene_of("cornell"))
+    g = golden("image_cornell_128_64spp.npz")
+    cam = pkg.abi.camera_from_numpy(g["camera"])
+    sums, dropped = oracle.render(sc, cam, 0, int(g["spp"]), int(g["depth"]), int(g["seed"]), threads=8)
+    assert dropped == int(g["dropped"])
+    assert np.array_equal(sums, g["sums"])
+    u = golden("unlit_cornell_128.npz")
+    assert np.array_equal(oracle.render_unlit(sc, pkg.abi.camera_from_numpy(u["camera"])), u["color"])
+
+
+def test_brdf_and_hemisphere(oracle, pkg, golden):
+    g = golden("brdf_hemisphere.npz")
+    for tag, rough in (("on_05", 0.5), ("on_10", 1.0), ("on_02", 0.2)):
+        m = pkg.abi.Material()
+        m.color[:] = (1, 1, 1); m.diffuse = pkg.abi.DIFFUSE_OREN_NAYAR; m.albedo = 1.0; m.roughness = rough; m.refractive_index = 1.52
+        out = oracle.brdf(m, g["incident"], g["reflection"], g["normals"])
+        assert np.array_equal(out.view(np.uint64), g[f"brdf_{tag}"].view(np.uint64))
+    assert np.isnan(g["brdf_on_05"][:16]).any(), "fixture should contain the acos-domain NaN case"
+    d, c = oracle.hemisphere(g["normals"], g["states"])
+    assert np.array_equal(d.view(np.uint32), g["hemi_dir"].view(np.uint32)) and np.array_equal(c, g["hemi_cos"])
+    d, c = oracle.hemisphere(g["axis_normals"], g["states"][:600])
+    assert np.array_equal(d.view(np.uint32), g["hemi_dir_axis"].view(np.uint32)) and np.array_equal(c, g["hemi_cos_axis"])
+
+
+def test_tonemap_table(oracle, pkg, golden):
+    g = golden("tonemap.npz")
+    spp = int(g["spp"])
+    b, mean = oracle.resolve(g["sums"], spp, pkg.abi.TONEMAP_REINHARD)
+    assert np.array_equal(b, g["reinhard"]) and np.array_equal(mean, g["mean"])
+    assert np.array_equal(oracle.resolve(g["sums"], spp, pkg.abi.TONEMAP_EXPOSURE, exposure=1.0)[0], g["exposure"])
+    assert np.array_equal(oracle.resolve(g["sums"], spp, pkg.abi.TONEMAP_EXPOSURE, gamma=1.8, exposure=0.35)[0], g["exposure_g18_e035"])
+    assert np.array_equal(oracle.resolve(g["sums"], spp, pkg.abi.TONEMAP_NONE)[0], g["none"])
+
+
+def test_oracle_against_live_reference(oracle, ref, scene_of):
+    """Where the reference build is present: fresh random samples, not only the stored ones."""
+    rng = np.random.default_rng(7)
+    flat = scene_of("config3")
+    cam_r = ref.camera(256, 192, 75.0, (0.5, 0.2, 5), (0, -0.5, 0))
+    cam_o = oracle.camera(256, 192, 75.0, (0.5, 0.2, 5), (0, -0.5, 0))
+    assert bytes(cam_r) == bytes(cam_o)
+    px = rng.integers(0, 256 * 192, 3000).astype(np.uint32)
+    sm = rng.integers(0, 1 << 20, 3000).astype(np.uint32)
+    a = ref.trace_samples(ref.scene(flat), cam_r, px, sm, 99, 100)
+    b = oracle.trace_samples(oracle.scene(flat), cam_o, px, sm, 99, 100)
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
