@@ -149,6 +149,12 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* scene,
  * the PixelBuffer accumulators (source/core/pixelbuffer.cpp:7-23). */
 int mcrt_set_camera(mcrt_ctx* ctx, const mcrt_camera* camera);
 
+/* Host-only helper: fill an mcrt_camera the way the reference does -
+ * Camera::Camera (fovPixelScale = tan(fovY/2), source/core/camera.h:19-26) and
+ * Camera::SetView (inverse(glm::lookAtRH), :30-34). */
+int mcrt_camera_look_at(uint32_t width, uint32_t height, float fov_y_degrees, const float position[3],
+                        const float look_at[3], const float up[3], mcrt_camera* out);
+
 /* Choose MCRT_ACCEL_OCTREE (default) or MCRT_ACCEL_BRUTE for later calls. */
 int mcrt_set_accel(mcrt_ctx* ctx, int accel_mode);
 

@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "mcrt_camera_rays", "mcrt_intersect", "mcrt_intersect_device", "mcrt_trace_samples", "mcrt_render_unlit", "mcrt_rng_seed",
     "mcrt_clear", "mcrt_bind_accumulator", "mcrt_accumulator", "mcrt_render", "mcrt_last_render_ms", "mcrt_resolve",
     "mcrt_read_accumulator", "mcrt_synchronize", "mcrt_octree_info_get", "mcrt_octree_download", "mcrt_set_counting", "mcrt_counters",
-    "mcrt_scene_image_create", "mcrt_scene_image_destroy", "mcrt_scene_image_info", "mcrt_scene_image_octree",
+    "mcrt_camera_look_at", "mcrt_scene_image_create", "mcrt_scene_image_destroy", "mcrt_scene_image_info", "mcrt_scene_image_octree",
 )
 
 _lib = None
@@ -62,6 +62,18 @@ def _f32(a):
 
 def _ptr(a, t):
     return a.ctypes.data_as(C.POINTER(t))
+
+
+def host_camera(width, height, fov_y, position, look_at, up=(0.0, 1.0, 0.0)):
+    """Camera ctor + SetView on the host (mcrt_camera_look_at)."""
+    cam = Camera()
+    rc = load_library().mcrt_camera_look_at(
+        C.c_uint32(width), C.c_uint32(height), C.c_float(fov_y), _ptr(_f32(position), C.c_float), _ptr(_f32(look_at), C.c_float),
+        _ptr(_f32(up), C.c_float), C.byref(cam),
+    )
+    if rc:
+        raise McrtError(rc, (load_library().mcrt_last_error(None) or b"").decode())
+    return cam
 
 
 def build_scene_image(flat, accel=None):

@@ -728,6 +728,15 @@ int mcrt_set_camera(mcrt_ctx* c, const mcrt_camera* cam)
     return MCRT_OK;
 }
 
+int mcrt_camera_look_at(uint32_t width, uint32_t height, float fov_y_degrees, const float position[3], const float look_at[3],
+                        const float up[3], mcrt_camera* out)
+{
+    if (!position || !look_at || !up || !out) return fail(nullptr, MCRT_ERR_INVALID, "null argument");
+    if (width == 0 || height == 0) return fail(nullptr, MCRT_ERR_INVALID, "bad image size");
+    camera_look_at(width, height, fov_y_degrees, position, look_at, up, out);
+    return MCRT_OK;
+}
+
 int mcrt_set_accel(mcrt_ctx* c, int mode)
 {
     if (!c) return MCRT_ERR_INVALID;

@@ -147,6 +147,61 @@ bool finite3(const float* v) { return std::isfinite(v[0]) && std::isfinite(v[1])
 
 } // namespace
 
+namespace {
+struct F3 { float x, y, z; };
+inline F3 sub3(F3 a, F3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+inline float dot3(F3 a, F3 b) { float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z; return tx + ty + tz; }
+inline F3 cross3(F3 x, F3 y) { return { x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y }; }
+inline F3 norm3(F3 v) { float inv = 1.0f / std::sqrt(dot3(v, v)); return { v.x * inv, v.y * inv, v.z * inv }; }
+} // namespace
+
+void camera_look_at(uint32_t width, uint32_t height, float fov_y_degrees, const float position[3], const float look_at[3],
+                    const float up[3], mcrt_camera* out)
+{
+    // Camera ctor, source/core/camera.h:23-25
+    const float halfAngle = fov_y_degrees * 0.5f;
+    const float radians = halfAngle / 180.0f * float(3.14159265358979323846264338327950288);
+    out->fov_scale = std::tan(radians);
+    // glm::lookAtRH, include/glm/ext/matrix_transform.inl:99-119
+    const F3 eye{ position[0], position[1], position[2] }, centre{ look_at[0], look_at[1], look_at[2] }, upv{ up[0], up[1], up[2] };
+    const F3 f = norm3(sub3(centre, eye));
+    const F3 s = norm3(cross3(f, upv));
+    const F3 u = cross3(s, f);
+    float m[4][4] = { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 }, { 0, 0, 0, 1 } };   // m[column][row]
+    m[0][0] = s.x; m[1][0] = s.y; m[2][0] = s.z;
+    m[0][1] = u.x; m[1][1] = u.y; m[2][1] = u.z;
+    m[0][2] = -f.x; m[1][2] = -f.y; m[2][2] = -f.z;
+    m[3][0] = -dot3(s, eye); m[3][1] = -dot3(u, eye); m[3][2] = dot3(f, eye);
+    // glm::inverse(mat4): cofactor expansion, include/glm/detail/func_matrix.inl:294-352
+    float c[6][3];   // the six 2x2 sub-determinant triples (Coef00..Coef23 grouped as Fac0..Fac5 uses them)
+    const int pairs[6][2] = { { 2, 3 }, { 1, 3 }, { 1, 2 }, { 0, 3 }, { 0, 2 }, { 0, 1 } };   // row pairs of each Fac
+    (void)pairs;
+    auto det2 = [&](int ca, int ra, int cb, int rb) { return m[ca][ra] * m[cb][rb] - m[cb][ra] * m[ca][rb]; };
+    // Fac0: rows (2,3); Fac1: rows (1,3); Fac2: rows (1,2); Fac3: rows (0,3); Fac4: rows (0,2); Fac5: rows (0,1);
+    // each over column pairs (2,3), (1,3), (1,2)
+    const int rows[6][2] = { { 2, 3 }, { 1, 3 }, { 1, 2 }, { 0, 3 }, { 0, 2 }, { 0, 1 } };
+    const int cols[3][2] = { { 2, 3 }, { 1, 3 }, { 1, 2 } };
+    for (int k = 0; k < 6; ++k)
+        for (int j = 0; j < 3; ++j) c[k][j] = det2(cols[j][0], rows[k][0], cols[j][1], rows[k][1]);
+    float inv[4][4];
+    const float signA[4] = { +1, -1, +1, -1 }, signB[4] = { -1, +1, -1, +1 };
+    for (int i = 0; i < 4; ++i) {
+        const int j = i < 2 ? 0 : i - 1;                 // Fac = (Coef_a, Coef_a, Coef_b, Coef_c)
+        const int col = i == 0 ? 1 : 0;                  // Vec = (m[1][r], m[0][r], m[0][r], m[0][r])
+        const float v0 = m[col][0], v1 = m[col][1], v2 = m[col][2], v3 = m[col][3];
+        inv[0][i] = ((v1 * c[0][j] - v2 * c[1][j]) + v3 * c[2][j]) * signA[i];
+        inv[1][i] = ((v0 * c[0][j] - v2 * c[3][j]) + v3 * c[4][j]) * signB[i];
+        inv[2][i] = ((v0 * c[1][j] - v1 * c[3][j]) + v3 * c[5][j]) * signA[i];
+        inv[3][i] = ((v0 * c[2][j] - v1 * c[4][j]) + v2 * c[5][j]) * signB[i];
+    }
+    const float d0 = m[0][0] * inv[0][0], d1 = m[0][1] * inv[1][0], d2 = m[0][2] * inv[2][0], d3 = m[0][3] * inv[3][0];
+    const float one_over_det = 1.0f / ((d0 + d1) + (d2 + d3));
+    for (int col = 0; col < 4; ++col)
+        for (int row = 0; row < 4; ++row) out->view[col * 4 + row] = inv[col][row] * one_over_det;
+    out->position[0] = position[0]; out->position[1] = position[1]; out->position[2] = position[2];
+    out->width = width; out->height = height;
+}
+
 int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, FlatScene& out, std::string& err)
 {
     if (!sc || (sc->object_count && !sc->objects) || (sc->triangle_count && !sc->triangles)) { err = "null scene description"; return MCRT_ERR_INVALID; }

@@ -351,8 +351,9 @@ void ref_surface_normal(void* h, uint64_t n, const int32_t* obj, const uint32_t*
 void ref_trace_rays(void* h, uint64_t n, const float* o, const float* d, const uint64_t* states, uint32_t depth, double* out)
 {
     Scene& s = *static_cast<RefScene*>(h)->scene;
+    SeedableRng g;
     for (uint64_t i = 0; i < n; ++i) {
-        SeedableRng g; g.Seed(states[2 * i], states[2 * i + 1]);
+        g.Seed(states[2 * i], states[2 * i + 1]);
         ColorDbl c = s.TraceRay(Ray(Get3(o + 3 * i), Get3(d + 3 * i)), g, depth);
         out[3 * i] = c.r; out[3 * i + 1] = c.g; out[3 * i + 2] = c.b;
     }
@@ -360,11 +361,13 @@ void ref_trace_rays(void* h, uint64_t n, const float* o, const float* d, const u
 
 /* One iteration of the spp loop of source/main.cpp:122-139 for listed
  * (pixel, sample) pairs; jitter and TraceRay share the per-sample stream. */
-static inline ColorDbl OneSample(Scene& s, CameraAccess& c, uint32_t pixel, uint32_t sample, uint64_t seed, uint32_t depth)
+/* `g` is constructed once per thread: UniformRandomGenerator's ctor reads std::random_device
+ * (source/core/randomization.cpp:8-13), far too slow to run per sample; its state is overwritten here. */
+static inline ColorDbl OneSample(Scene& s, CameraAccess& c, SeedableRng& g, uint32_t pixel, uint32_t sample, uint64_t seed, uint32_t depth)
 {
     uint64_t st[2];
     SampleSeed(seed, pixel, sample, st);
-    SeedableRng g; g.Seed(st[0], st[1]);
+    g.Seed(st[0], st[1]);
     uint32_t w = uint32_t(c.pixels.width());
     uint32_t x = pixel % w, y = pixel / w;
     float sx = g.RandomFloat();
@@ -377,8 +380,9 @@ void ref_trace_samples(void* h, void* cv, uint64_t n, const uint32_t* pixels, co
 {
     Scene& s = *static_cast<RefScene*>(h)->scene;
     CameraAccess& c = *static_cast<CameraAccess*>(cv);
+    SeedableRng g;
     for (uint64_t i = 0; i < n; ++i) {
-        ColorDbl v = OneSample(s, c, pixels[i], samples[i], seed, depth);
+        ColorDbl v = OneSample(s, c, g, pixels[i], samples[i], seed, depth);
         out[3 * i] = v.r; out[3 * i + 1] = v.g; out[3 * i + 2] = v.b;
     }
 }
@@ -400,12 +404,13 @@ uint64_t ref_render(void* h, void* cv, uint32_t sample_begin, uint32_t sample_co
     std::atomic<uint64_t> dropped{ 0 };
     auto worker = [&]() {
         uint64_t myDropped = 0;
+        SeedableRng rng;
         for (;;) {
             uint32_t p = next.fetch_add(1, std::memory_order_relaxed);
             if (p >= npix) break;
             double r = 0.0, g = 0.0, b = 0.0;
             for (uint32_t k = 0; k < sample_count; ++k) {
-                ColorDbl v = OneSample(s, c, p, sample_begin + k, seed, depth);
+                ColorDbl v = OneSample(s, c, rng, p, sample_begin + k, seed, depth);
                 if (Finite3(v)) { r += v.r; g += v.g; b += v.b; } else ++myDropped;
             }
             out_sums[3 * size_t(p)] += r; out_sums[3 * size_t(p) + 1] += g; out_sums[3 * size_t(p) + 2] += b;
