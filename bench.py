@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="config2_1024_256", choices=sorted(WORKLOADS))
-    ap.add_argument("--accel", default="octree", choices=["octree", "brute"])
+    ap.add_argument("--accel", default="auto", choices=["auto", "octree", "scan", "brute"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -88,7 +88,7 @@ def main():
     be.set_stream(stream.cuda_stream)
     be.upload_scene(flat)
     be.set_camera(cam)
-    be.set_accel(pkg.ACCEL_OCTREE if args.accel == "octree" else pkg.ACCEL_BRUTE)
+    be.set_accel({"auto": pkg.ACCEL_AUTO, "octree": pkg.ACCEL_OCTREE, "scan": pkg.ACCEL_SCAN, "brute": pkg.ACCEL_BRUTE}[args.accel])
     accum = torch.zeros(height * width * 3, dtype=torch.float64, device="cuda")
     be.bind_accumulator(accum.data_ptr())
     first_sample = rank * spp                     # global sample indices of this rank

@@ -104,10 +104,18 @@ typedef struct mcrt_camera {
     uint32_t height;
 } mcrt_camera;
 
-/* How nearest-hit queries walk the scene. Results are identical by
- * construction; BRUTE restates source/scene.cpp:62-80 literally and is the
- * on-device cross-check for the octree. */
-enum { MCRT_ACCEL_OCTREE = 0, MCRT_ACCEL_BRUTE = 1 };
+/* How nearest-hit queries walk the scene.  Results are identical by
+ * construction.
+ *   OCTREE  per-lane stack traversal of the flat octree (any scene size);
+ *   BRUTE   source/scene.cpp:62-80 restated literally (on-device cross-check);
+ *   SCAN    wave-uniform walk of the object list with per-mesh gates, geometry
+ *           through scalar loads - the fast path for scenes of a few hundred
+ *           primitives, where 64 lanes on 64 different tree paths lose to one
+ *           lock-step pass;
+ *   AUTO    SCAN when the scene has at most MCRT_SCAN_MAX_PRIMS primitives,
+ *           OCTREE otherwise (default). */
+enum { MCRT_ACCEL_OCTREE = 0, MCRT_ACCEL_BRUTE = 1, MCRT_ACCEL_SCAN = 2, MCRT_ACCEL_AUTO = 3 };
+#define MCRT_SCAN_MAX_PRIMS 256
 
 typedef struct mcrt_accel_params {
     uint32_t max_leaf_prims;   /* Octree::maxCount analogue (octree.h:31); 0 = default */
@@ -155,7 +163,7 @@ int mcrt_set_camera(mcrt_ctx* ctx, const mcrt_camera* camera);
 int mcrt_camera_look_at(uint32_t width, uint32_t height, float fov_y_degrees, const float position[3],
                         const float look_at[3], const float up[3], mcrt_camera* out);
 
-/* Choose MCRT_ACCEL_OCTREE (default) or MCRT_ACCEL_BRUTE for later calls. */
+/* Choose MCRT_ACCEL_AUTO (default), _OCTREE, _SCAN or _BRUTE for later calls. */
 int mcrt_set_accel(mcrt_ctx* ctx, int accel_mode);
 
 /* ------------------------------------------------------------ parity paths */

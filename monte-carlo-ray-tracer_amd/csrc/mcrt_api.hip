@@ -63,6 +63,28 @@ template <> __device__ __forceinline__ LdsPtr big_ptr<true>(const SceneView& v, 
 }
 template <> __device__ __forceinline__ GlbPtr big_ptr<false>(const SceneView& v, uint32_t*) { return v.big_img; }
 
+// Where a kernel reads the scene images from: LDS copies (octree / brute), or straight from
+// global memory through the constant address space (scan: wave-uniform addresses -> scalar loads).
+template <bool kBigLds, int kAccel> struct SceneMem {
+    typedef LdsPtr PS;
+    typedef typename BigPtr<kBigLds>::type PB;
+    static __device__ __forceinline__ void open(const SceneView& v, uint32_t* smem, PS& sm, PB& big)
+    {
+        stage_scene<kBigLds>(v, smem);
+        sm = (LdsPtr)smem;
+        big = big_ptr<kBigLds>(v, smem);
+    }
+};
+template <bool kBigLds> struct SceneMem<kBigLds, MCRT_ACCEL_SCAN> {
+    typedef CstPtr PS;
+    typedef CstPtr PB;
+    static __device__ __forceinline__ void open(const SceneView& v, uint32_t*, PS& sm, PB& big)
+    {
+        sm = (CstPtr)v.small_img;
+        big = (CstPtr)v.big_img;
+    }
+};
+
 // ------------------------------------------------------------ parked branches
 // Reflect branches of refractive splits (source/scene.cpp:212-213) wait here while the refract
 // branch runs.  One column per launched lane; fields interleaved so a wave touches consecutive words.
@@ -294,9 +316,10 @@ template <bool kBigLds, int kAccel, bool kCount>
 __global__ __launch_bounds__(kBlock) void k_render(const RenderArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    stage_scene<kBigLds>(a.view, smem);
-    const LdsPtr sm = (LdsPtr)smem;
-    const typename BigPtr<kBigLds>::type big = big_ptr<kBigLds>(a.view, smem);
+    typedef SceneMem<kBigLds, kAccel> Mem;
+    typename Mem::PS sm;
+    typename Mem::PB big;
+    Mem::open(a.view, smem, sm, big);
 
     PendStack pend;
     pend.base = a.pend;
@@ -318,7 +341,7 @@ __global__ __launch_bounds__(kBlock) void k_render(const RenderArgs a)
         const bool inside = x < a.cam.width && y < a.cam.height;
         const uint32_t pixel = inside ? y * a.cam.width + x : 0u;
         D3 sum; uint32_t dropped;
-        trace_lane<LdsPtr, typename BigPtr<kBigLds>::type, kAccel, kCount>(sm, big, a.view, a.cam, pixel, a.s_begin, inside ? a.s_count : 0u,
+        trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, pixel, a.s_begin, inside ? a.s_count : 0u,
                                                                           a.seed, a.max_depth, pend, false, sum, dropped, cn, rc);
         if (inside) {
             double* px = a.accum + (size_t)pixel * 3;
@@ -347,9 +370,10 @@ template <bool kBigLds, int kAccel, bool kCount>
 __global__ __launch_bounds__(kBlock) void k_trace_list(const ListArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    stage_scene<kBigLds>(a.view, smem);
-    const LdsPtr sm = (LdsPtr)smem;
-    const typename BigPtr<kBigLds>::type big = big_ptr<kBigLds>(a.view, smem);
+    typedef SceneMem<kBigLds, kAccel> Mem;
+    typename Mem::PS sm;
+    typename Mem::PB big;
+    Mem::open(a.view, smem, sm, big);
     PendStack pend;
     pend.base = a.pend;
     pend.lanes = gridDim.x * blockDim.x;
@@ -358,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_list(const ListArgs a)
     RenderCounters rc = { 0, 0, 0 };
     for (uint64_t i = pend.lane; i < a.n; i += pend.lanes) {
         D3 sum; uint32_t dropped;
-        trace_lane<LdsPtr, typename BigPtr<kBigLds>::type, kAccel, kCount>(sm, big, a.view, a.cam, a.pixels[i], a.samples[i], 1u, a.seed,
+        trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, a.pixels[i], a.samples[i], 1u, a.seed,
                                                                           a.max_depth, pend, true, sum, dropped, cn, rc);
         a.out[3 * i] = sum.x; a.out[3 * i + 1] = sum.y; a.out[3 * i + 2] = sum.z;
     }
@@ -371,16 +395,17 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const SceneView v, uint64_
                                                       unsigned long long* counters)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    stage_scene<kBigLds>(v, smem);
-    const LdsPtr sm = (LdsPtr)smem;
-    const typename BigPtr<kBigLds>::type big = big_ptr<kBigLds>(v, smem);
+    typedef SceneMem<kBigLds, kAccel> Mem;
+    typename Mem::PS sm;
+    typename Mem::PB big;
+    Mem::open(v, smem, sm, big);
     Counters cn = { 0, 0, 0, 0, 0 };
     RenderCounters rc = { 0, 0, 0 };
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const V3 ro = mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
         const V3 rd = mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-        const Hit h = cast<kAccel, LdsPtr, typename BigPtr<kBigLds>::type, kCount>(sm, big, v, ro, rd, cn);
+        const Hit h = cast<kAccel, typename Mem::PS, typename Mem::PB, kCount>(sm, big, v, ro, rd, cn);
         out_obj[i] = (h.obj == MISS) ? -1 : (int32_t)h.obj;
         out_elem[i] = h.elem;
         out_t[i] = h.t;
@@ -404,9 +429,10 @@ template <bool kBigLds, int kAccel>
 __global__ __launch_bounds__(kBlock) void k_unlit(const SceneView v, const CameraDev cam, double* __restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    stage_scene<kBigLds>(v, smem);
-    const LdsPtr sm = (LdsPtr)smem;
-    const typename BigPtr<kBigLds>::type big = big_ptr<kBigLds>(v, smem);
+    typedef SceneMem<kBigLds, kAccel> Mem;
+    typename Mem::PS sm;
+    typename Mem::PB big;
+    Mem::open(v, smem, sm, big);
     Counters cn = { 0, 0, 0, 0, 0 };
     const uint64_t npix = (uint64_t)cam.width * cam.height;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -414,7 +440,7 @@ __global__ __launch_bounds__(kBlock) void k_unlit(const SceneView v, const Camer
         const uint32_t x = (uint32_t)(i % cam.width), y = (uint32_t)(i / cam.width);
         V3 o, d;
         camera_ray(cam, (float)x + 0.5f, (float)y + 0.5f, o, d);     // source/main.cpp:126
-        const Hit h = cast<kAccel, LdsPtr, typename BigPtr<kBigLds>::type, false>(sm, big, v, o, d, cn);
+        const Hit h = cast<kAccel, typename Mem::PS, typename Mem::PB, false>(sm, big, v, o, d, cn);
         D3 c = dmk(0.0, 0.0, 0.0);
         if (h.obj != MISS) c = ldd3(sm, v.off_obj + h.obj * OBJ_STRIDE + OBJ_COLOR);
         out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
@@ -480,7 +506,8 @@ struct mcrt_ctx {
     size_t accum_pixels = 0;
     double* d_accum = nullptr;
 
-    int accel = MCRT_ACCEL_OCTREE;
+    int accel_request = MCRT_ACCEL_AUTO;   // what the caller asked for
+    int accel = MCRT_ACCEL_OCTREE;         // what kernels run with (AUTO resolved per scene)
     bool counting = false;
     unsigned long long* d_counters = nullptr;   // 8 x u64
     uint32_t* d_tile = nullptr;                 // 2 x u32
@@ -508,6 +535,14 @@ int fail(mcrt_ctx* c, int code, const std::string& msg)
 
 int bind_device(mcrt_ctx* c) { HIP_TRY(c, hipSetDevice(c->device)); return MCRT_OK; }
 
+size_t lds_for(const mcrt_ctx* c) { return c->accel == MCRT_ACCEL_SCAN ? 0 : c->lds_bytes; }
+
+void resolve_accel(mcrt_ctx* c)
+{
+    c->accel = c->accel_request;
+    if (c->accel == MCRT_ACCEL_AUTO) c->accel = (c->have_scene && c->view.nprim <= MCRT_SCAN_MAX_PRIMS) ? MCRT_ACCEL_SCAN : MCRT_ACCEL_OCTREE;
+}
+
 // persistent grid: enough 256-lane workgroups to fill every CU at the occupancy the kernel can reach
 uint32_t grid_for(const mcrt_ctx* c) { return (uint32_t)c->cu_count * 8u; }
 
@@ -533,18 +568,18 @@ template <class K> int set_lds_limit(mcrt_ctx* c, K kernel, size_t bytes)
 template <bool kBigLds, int kAccel, bool kCount> int launch_render_t(mcrt_ctx* c, const RenderArgs& a)
 {
     auto kern = k_render<kBigLds, kAccel, kCount>;
-    int rc = set_lds_limit(c, kern, c->lds_bytes);
+    int rc = set_lds_limit(c, kern, lds_for(c));
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid_for(c)), dim3(kBlock), c->lds_bytes, c->stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid_for(c)), dim3(kBlock), lds_for(c), c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return MCRT_OK;
 }
 template <bool kBigLds, int kAccel, bool kCount> int launch_list_t(mcrt_ctx* c, const ListArgs& a)
 {
     auto kern = k_trace_list<kBigLds, kAccel, kCount>;
-    int rc = set_lds_limit(c, kern, c->lds_bytes);
+    int rc = set_lds_limit(c, kern, lds_for(c));
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid_for(c)), dim3(kBlock), c->lds_bytes, c->stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid_for(c)), dim3(kBlock), lds_for(c), c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return MCRT_OK;
 }
@@ -552,20 +587,20 @@ template <bool kBigLds, int kAccel, bool kCount>
 int launch_intersect_t(mcrt_ctx* c, uint64_t n, const float* o, const float* d, int32_t* obj, uint32_t* elem, float* t)
 {
     auto kern = k_intersect<kBigLds, kAccel, kCount>;
-    int rc = set_lds_limit(c, kern, c->lds_bytes);
+    int rc = set_lds_limit(c, kern, lds_for(c));
     if (rc) return rc;
     uint32_t blocks = (uint32_t)std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)grid_for(c) * 4);
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kBlock), c->lds_bytes, c->stream, c->view, n, o, d, obj, elem, t, c->d_counters);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kBlock), lds_for(c), c->stream, c->view, n, o, d, obj, elem, t, c->d_counters);
     HIP_TRY(c, hipGetLastError());
     return MCRT_OK;
 }
 template <bool kBigLds, int kAccel> int launch_unlit_t(mcrt_ctx* c, double* out)
 {
     auto kern = k_unlit<kBigLds, kAccel>;
-    int rc = set_lds_limit(c, kern, c->lds_bytes);
+    int rc = set_lds_limit(c, kern, lds_for(c));
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid_for(c)), dim3(kBlock), c->lds_bytes, c->stream, c->view, c->cam, out);
+    hipLaunchKernelGGL(kern, dim3(grid_for(c)), dim3(kBlock), lds_for(c), c->stream, c->view, c->cam, out);
     HIP_TRY(c, hipGetLastError());
     return MCRT_OK;
 }
@@ -574,6 +609,10 @@ template <bool kBigLds, int kAccel> int launch_unlit_t(mcrt_ctx* c, double* out)
 #define MCRT_DISPATCH(c, CALL_, ...)                                                                                   \
     do {                                                                                                                \
         const bool lds_ = (c)->big_in_lds;                                                                              \
+        if ((c)->accel == MCRT_ACCEL_SCAN) {                                                                            \
+            if ((c)->counting) return CALL_<false, MCRT_ACCEL_SCAN, true>(__VA_ARGS__);                                \
+            return CALL_<false, MCRT_ACCEL_SCAN, false>(__VA_ARGS__);                                                   \
+        }                                                                                                               \
         if ((c)->accel == MCRT_ACCEL_BRUTE) {                                                                           \
             if ((c)->counting) return lds_ ? CALL_<true, MCRT_ACCEL_BRUTE, true>(__VA_ARGS__) : CALL_<false, MCRT_ACCEL_BRUTE, true>(__VA_ARGS__);   \
             return lds_ ? CALL_<true, MCRT_ACCEL_BRUTE, false>(__VA_ARGS__) : CALL_<false, MCRT_ACCEL_BRUTE, false>(__VA_ARGS__);                    \
@@ -590,6 +629,7 @@ int launch_intersect(mcrt_ctx* c, uint64_t n, const float* o, const float* d, in
 }
 int launch_unlit(mcrt_ctx* c, double* out)
 {
+    if (c->accel == MCRT_ACCEL_SCAN) return launch_unlit_t<false, MCRT_ACCEL_SCAN>(c, out);
     if (c->accel == MCRT_ACCEL_BRUTE) return c->big_in_lds ? launch_unlit_t<true, MCRT_ACCEL_BRUTE>(c, out) : launch_unlit_t<false, MCRT_ACCEL_BRUTE>(c, out);
     return c->big_in_lds ? launch_unlit_t<true, MCRT_ACCEL_OCTREE>(c, out) : launch_unlit_t<false, MCRT_ACCEL_OCTREE>(c, out);
 }
@@ -697,6 +737,7 @@ int mcrt_upload_scene(mcrt_ctx* c, const mcrt_scene_desc* scene, const mcrt_acce
     c->big_in_lds = all_bytes <= kLdsBudgetBytes;
     c->lds_bytes = c->big_in_lds ? all_bytes : small_bytes;
     c->have_scene = true;
+    resolve_accel(c);
     return MCRT_OK;
 }
 
@@ -740,8 +781,9 @@ int mcrt_camera_look_at(uint32_t width, uint32_t height, float fov_y_degrees, co
 int mcrt_set_accel(mcrt_ctx* c, int mode)
 {
     if (!c) return MCRT_ERR_INVALID;
-    if (mode != MCRT_ACCEL_OCTREE && mode != MCRT_ACCEL_BRUTE) return fail(c, MCRT_ERR_INVALID, "unknown accel mode");
-    c->accel = mode;
+    if (mode < MCRT_ACCEL_OCTREE || mode > MCRT_ACCEL_AUTO) return fail(c, MCRT_ERR_INVALID, "unknown accel mode");
+    c->accel_request = mode;
+    resolve_accel(c);
     return MCRT_OK;
 }
 

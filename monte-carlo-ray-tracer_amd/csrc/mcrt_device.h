@@ -56,6 +56,25 @@ MCRT_DEV D3 ddivs(D3 a, double s) { return dmk(a.x / s, a.y / s, a.z / s); }
 // P is either an LDS pointer (address_space(3)) or a global pointer.
 typedef const __attribute__((address_space(3))) uint32_t* LdsPtr;
 typedef const uint32_t* GlbPtr;
+// constant address space: loads with a wave-uniform address become scalar (SMEM) loads into SGPRs
+typedef const __attribute__((address_space(4))) uint32_t* CstPtr;
+
+// 16-byte loads (index must be a multiple of 4 words): ds_read_b128 / global_load_dwordx4 / s_load_dwordx4
+typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+MCRT_DEV U4 ld4(LdsPtr p, uint32_t i) { return *(const __attribute__((address_space(3))) U4*)(p + i); }
+MCRT_DEV U4 ld4(GlbPtr p, uint32_t i) { return *(const U4*)(p + i); }
+MCRT_DEV U4 ld4(CstPtr p, uint32_t i) { return *(const __attribute__((address_space(4))) U4*)(p + i); }
+
+struct TriRec { V3 v0, e1, e2; };
+template <class P> MCRT_DEV TriRec load_tri(P big, uint32_t rec)
+{
+    const U4 a = ld4(big, rec), b = ld4(big, rec + 4), c = ld4(big, rec + 8);
+    TriRec t;
+    t.v0 = mk(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+    t.e1 = mk(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
+    t.e2 = mk(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x));
+    return t;
+}
 
 template <class P> MCRT_DEV float ldf(P p, uint32_t i) { return __uint_as_float(p[i]); }
 template <class P> MCRT_DEV V3 ld3(P p, uint32_t i) { return mk(ldf(p, i), ldf(p, i + 1), ldf(p, i + 2)); }
@@ -212,9 +231,8 @@ MCRT_DEV float pm_acosf(float xf)
 // Triangle::Intersects, source/core/triangle.h:25-62 (edges precomputed at upload).
 template <class P> MCRT_DEV bool tri_hit(P big, uint32_t rec, V3 o, V3 d, float& t)
 {
-    V3 v0 = ld3(big, rec + TRI_V0);
-    V3 edge1 = ld3(big, rec + TRI_E1);
-    V3 edge2 = ld3(big, rec + TRI_E2);
+    const TriRec tr = load_tri(big, rec);
+    const V3 v0 = tr.v0, edge1 = tr.e1, edge2 = tr.e2;
     V3 h = cross(d, edge2);
     float a = dot(edge1, h);
     if (fabsf(a) < kFltEpsilon) return false;
@@ -232,10 +250,11 @@ template <class P> MCRT_DEV bool tri_hit(P big, uint32_t rec, V3 o, V3 d, float&
 // SphereObject::Intersects, source/objects/sphere.h:16-52
 template <class P> MCRT_DEV bool sphere_hit(P sm, uint32_t orec, V3 o, V3 d, float& t)
 {
-    float radius = ldf(sm, orec + OBJ_RADIUS);
+    const U4 rp = ld4(sm, orec + OBJ_RADIUS);        // radius, position.xyz
+    float radius = __uint_as_float(rp.x);
     if (radius < kFltEpsilon) return false;
     float radiusSq = radius * radius;
-    V3 L = ld3(sm, orec + OBJ_POS) - o;
+    V3 L = mk(__uint_as_float(rp.y), __uint_as_float(rp.z), __uint_as_float(rp.w)) - o;
     float tca = dot(L, d);
     if (tca < 0) return false;
     float distanceSq = dot(L, L) - tca * tca;
@@ -259,11 +278,14 @@ template <class P> MCRT_DEV bool gate_hit(P sm, uint32_t orec, V3 o, V3 d)
 {
     float tmin = -kFltMax, tmax = kFltMax;
     const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+    const U4 b0 = ld4(sm, orec + OBJ_AABB_MIN), b1 = ld4(sm, orec + OBJ_AABB_MIN + 4);
+    const float mn[3] = { __uint_as_float(b0.x), __uint_as_float(b0.y), __uint_as_float(b0.z) };
+    const float mx[3] = { __uint_as_float(b0.w), __uint_as_float(b1.x), __uint_as_float(b1.y) };
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         if (dd[a] != 0.0f) {
-            float t1 = (ldf(sm, orec + OBJ_AABB_MIN + a) - oo[a]) / dd[a];
-            float t2 = (ldf(sm, orec + OBJ_AABB_MAX + a) - oo[a]) / dd[a];
+            float t1 = (mn[a] - oo[a]) / dd[a];
+            float t2 = (mx[a] - oo[a]) / dd[a];
             float lo = (t2 < t1) ? t2 : t1;
             float hi = (t1 < t2) ? t2 : t1;
             tmin = (tmin < lo) ? lo : tmin;
@@ -411,10 +433,116 @@ MCRT_DEV Hit cast_octree(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters
     return best;
 }
 
+// ---------------------------------------------------------------- wave-uniform scan
+// Nearest hit for scenes small enough that a whole wavefront is better off walking the object
+// list in lock step than letting 64 lanes chase 64 different tree paths: every lane visits the
+// same object / triangle at the same time, so the geometry arrives through SCALAR loads (SGPR
+// operands, no LDS or VGPR traffic, no divergent control flow), a mesh is skipped for the whole
+// wave when no lane passes its gate, and the loop order IS the reference's order (objects, then
+// triangles), which gives its first-wins tie-break for free (source/scene.cpp:71-76).
+//
+// Arithmetic: rejections may be decided on cheap approximations (reciprocal-multiply instead of
+// IEEE division) as long as they are conservative; anything that can become the reported hit -
+// and every borderline case - is recomputed with the reference's exact operation sequence.
+
+// Triangle::Intersects (source/core/triangle.h:25-62) for "can this triangle beat best_t?".
+template <class P> MCRT_DEV bool tri_nearer(P big, uint32_t rec, V3 o, V3 d, float best_t, float& t_out)
+{
+    const TriRec tr = load_tri(big, rec);
+    const V3 v0 = tr.v0, edge1 = tr.e1, edge2 = tr.e2;
+    const V3 h = cross(d, edge2);
+    const float a = dot(edge1, h);
+    const V3 s = o - v0;
+    const float x = dot(s, h);
+    const V3 q = cross(s, edge1);
+    const float y = dot(d, q);
+    const float z = dot(edge2, q);
+    // approximate f: relative error of u', v', t' below 4e-7
+    const float fa = __builtin_amdgcn_rcpf(a);
+    const float ua = fa * x, va = fa * y, ta = fa * z;
+    const float m = 4.0e-6f;
+    const bool maybe = !(fabsf(a) < kFltEpsilon) && !(ua < -m) && !(ua > 1.0f + m) && !(va < -m) && !(ua + va > 1.0f + 2.0f * m) &&
+                       (ta > 0.5f * kFltEpsilon) && (ta < best_t * (1.0f + m));
+    bool hit = false;
+    if (maybe) {
+        const float f = 1.0f / a;
+        const float u = f * x;
+        if (!(u < 0.0f || u > 1.0f)) {
+            const float w = f * y;
+            if (!(w < 0.0f || u + w > 1.0f)) {
+                const float t = f * z;
+                if (t > kFltEpsilon && t < best_t) { t_out = t; hit = true; }
+            }
+        }
+    }
+    return hit;
+}
+
+// AABB::IntersectsRay (source/core/aabb.h:49-96): decided on reciprocal-multiply slabs when the
+// outcome is clear, on the exact quotients otherwise.  `inv` = approximate 1/d per axis; `exact_only`
+// is set for rays with a denormal-range direction component (their approximate slabs overflow).
+template <class P> MCRT_DEV bool gate_hit_fast(P sm, uint32_t orec, V3 o, V3 d, V3 inv, bool exact_only)
+{
+    float tmin = -kFltMax, tmax = kFltMax;
+    const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z }, ii[3] = { inv.x, inv.y, inv.z };
+    const U4 b0 = ld4(sm, orec + OBJ_AABB_MIN), b1 = ld4(sm, orec + OBJ_AABB_MIN + 4);
+    const float mn[3] = { __uint_as_float(b0.x), __uint_as_float(b0.y), __uint_as_float(b0.z) };
+    const float mx[3] = { __uint_as_float(b0.w), __uint_as_float(b1.x), __uint_as_float(b1.y) };
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float t1 = (mn[a] - oo[a]) * ii[a];
+        const float t2 = (mx[a] - oo[a]) * ii[a];
+        const float lo = (t2 < t1) ? t2 : t1;
+        const float hi = (t1 < t2) ? t2 : t1;
+        const bool use = dd[a] != 0.0f;
+        tmin = (use && tmin < lo) ? lo : tmin;
+        tmax = (use && hi < tmax) ? hi : tmax;
+    }
+    const float diff = tmax - tmin;
+    const float tol = 4.0e-6f * (fabsf(tmax) + fabsf(tmin)) + 1.0e-30f;
+    const bool clear_pass = diff > tol, clear_fail = diff < -tol;
+    if (!exact_only && (clear_pass || clear_fail)) return clear_pass;
+    return gate_hit(sm, orec, o, d);
+}
+
+template <class PS, class PB, bool kCount>
+MCRT_DEV Hit cast_scan(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters& cn)
+{
+    Hit best; best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax;
+    if (kCount) cn.rays++;
+    const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    const float tiny = 1.0e-20f;
+    const bool exact_only = (d.x != 0.0f && fabsf(d.x) < tiny) || (d.y != 0.0f && fabsf(d.y) < tiny) || (d.z != 0.0f && fabsf(d.z) < tiny);
+    for (uint32_t i = 0; i < v.nobj; ++i) {
+        const uint32_t orec = v.off_obj + i * OBJ_STRIDE;
+        const uint32_t kind = sm[orec + OBJ_KIND];
+        if (kind == MCRT_OBJECT_SPHERE) {
+            float t;
+            if (kCount) cn.spheres++;
+            if (sphere_hit(sm, orec, o, d, t) && t < best.t) { best.obj = i; best.elem = 0; best.t = t; }
+        } else {
+            if (kCount) cn.gates++;
+            const bool pass = gate_hit_fast(sm, orec, o, d, inv, exact_only);
+            if (__ballot(pass) == 0ull) continue;             // nobody in the wave needs this mesh
+            const uint32_t first = sm[orec + OBJ_FIRST_TRI], count = sm[orec + OBJ_TRI_COUNT];
+            for (uint32_t k = 0; k < count; ++k) {
+                if (pass) {
+                    float t;
+                    if (kCount) cn.tris++;
+                    if (tri_nearer(big, v.off_tri + (first + k) * TRI_STRIDE, o, d, best.t, t)) { best.obj = i; best.elem = k; best.t = t; }
+                }
+            }
+        }
+    }
+    if (best.obj != MISS) best.prim = sm[v.off_obj + best.obj * OBJ_STRIDE + OBJ_FIRST_PRIM] + best.elem;
+    return best;
+}
+
 template <int kAccel, class PS, class PB, bool kCount>
 MCRT_DEV Hit cast(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters& cn)
 {
     if (kAccel == MCRT_ACCEL_BRUTE) return cast_brute<PS, PB, kCount>(sm, big, v, o, d, cn);
+    if (kAccel == MCRT_ACCEL_SCAN) return cast_scan<PS, PB, kCount>(sm, big, v, o, d, cn);
     return cast_octree<PS, PB, kCount>(sm, big, v, o, d, cn);
 }
 

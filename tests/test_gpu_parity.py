@@ -33,15 +33,15 @@ def test_camera_rays_bit_exact(backend, pkg, golden, tag):
     assert np.array_equal(d.view(np.uint32), g["dirs"].view(np.uint32))
 
 
-@pytest.mark.parametrize("accel", ["octree", "brute"])
+@pytest.mark.parametrize("accel", ["octree", "brute", "scan"])
 @pytest.mark.parametrize("name", SCENES)
 def test_hits_bit_exact_vs_reference(backend, pkg, scene_of, golden, name, accel):
     """Fixed-ray queries: hit object, element index AND distance equal the reference's Scene::IntersectRay."""
     _upload(backend, pkg, scene_of, name)
-    backend.set_accel(pkg.ACCEL_OCTREE if accel == "octree" else pkg.ACCEL_BRUTE)
+    backend.set_accel({"octree": pkg.ACCEL_OCTREE, "brute": pkg.ACCEL_BRUTE, "scan": pkg.ACCEL_SCAN}[accel])
     g = golden(f"hits_{name}.npz")
     obj, elem, t = backend.intersect(g["origins"], g["dirs"])
-    backend.set_accel(pkg.ACCEL_OCTREE)
+    backend.set_accel(pkg.ACCEL_AUTO)
     bad = np.flatnonzero((obj != g["obj"]) | (elem != g["elem"]) | (t.view(np.uint32) != g["t"].view(np.uint32)))
     assert len(bad) == 0, f"{len(bad)} of {len(obj)} rays differ, first {bad[:5]}"
 
@@ -52,8 +52,10 @@ def test_hits_independent_of_octree_shape(backend, pkg, scene_of, golden, params
     accel = pkg.AccelParams(params[0], params[1], 0.0)
     for name in ("config2", "config4_2k"):
         _upload(backend, pkg, scene_of, name, accel)
+        backend.set_accel(pkg.ACCEL_OCTREE)
         g = golden(f"hits_{name}.npz")
         obj, elem, t = backend.intersect(g["origins"], g["dirs"])
+        backend.set_accel(pkg.ACCEL_AUTO)
         assert np.array_equal(obj, g["obj"]) and np.array_equal(elem, g["elem"]) and np.array_equal(t, g["t"])
 
 
@@ -79,17 +81,18 @@ def test_per_sample_radiance(backend, pkg, oracle, scene_of, golden, name):
     assert abs(np.nanmean(got) - np.nanmean(ref)) < 0.02 * abs(np.nanmean(ref)) + 1e-6
 
 
-def test_brute_and_octree_render_identically(backend, pkg, oracle, scene_of):
+def test_all_accel_modes_render_identically(backend, pkg, oracle, scene_of):
     flat = _upload(backend, pkg, scene_of, "config3")
     cam = oracle.camera(96, 64, 90.0, (0, 0, 5), (0, 0, 0))
     backend.set_camera(cam)
     backend.set_accel(pkg.ACCEL_BRUTE)
     backend.clear(); backend.render(0, 16, 100, SEED)
     a = backend.read_accumulator()
-    backend.set_accel(pkg.ACCEL_OCTREE)
-    backend.clear(); backend.render(0, 16, 100, SEED)
-    b = backend.read_accumulator()
-    assert np.array_equal(a, b)
+    for mode in (pkg.ACCEL_OCTREE, pkg.ACCEL_SCAN):
+        backend.set_accel(mode)
+        backend.clear(); backend.render(0, 16, 100, SEED)
+        assert np.array_equal(a, backend.read_accumulator())
+    backend.set_accel(pkg.ACCEL_AUTO)
     want, _ = oracle.render(oracle.scene(flat), cam, 0, 16, 100, SEED, threads=8, portable_math=True, forward_sum=True)
     assert np.array_equal(a, want), f"max abs diff {np.abs(a - want).max()}"
 
