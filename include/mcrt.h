@@ -116,6 +116,7 @@ typedef struct mcrt_camera {
  *           OCTREE otherwise (default). */
 enum { MCRT_ACCEL_OCTREE = 0, MCRT_ACCEL_BRUTE = 1, MCRT_ACCEL_SCAN = 2, MCRT_ACCEL_AUTO = 3 };
 #define MCRT_SCAN_MAX_PRIMS 256
+#define MCRT_SCAN_PAIR_LIMIT 65536   /* scenes with more triangles carry no scan records: SCAN is refused */
 
 typedef struct mcrt_accel_params {
     uint32_t max_leaf_prims;   /* Octree::maxCount analogue (octree.h:31); 0 = default */

@@ -737,6 +737,7 @@ int mcrt_upload_scene(mcrt_ctx* c, const mcrt_scene_desc* scene, const mcrt_acce
     c->big_in_lds = all_bytes <= kLdsBudgetBytes;
     c->lds_bytes = c->big_in_lds ? all_bytes : small_bytes;
     c->have_scene = true;
+    if (c->accel_request == MCRT_ACCEL_SCAN && !c->view.has_pairs) c->accel_request = MCRT_ACCEL_AUTO;   // scan cannot serve this scene
     resolve_accel(c);
     return MCRT_OK;
 }
@@ -782,6 +783,8 @@ int mcrt_set_accel(mcrt_ctx* c, int mode)
 {
     if (!c) return MCRT_ERR_INVALID;
     if (mode < MCRT_ACCEL_OCTREE || mode > MCRT_ACCEL_AUTO) return fail(c, MCRT_ERR_INVALID, "unknown accel mode");
+    if (mode == MCRT_ACCEL_SCAN && c->have_scene && !c->view.has_pairs)
+        return fail(c, MCRT_ERR_LIMIT, "scene has more than MCRT_SCAN_PAIR_LIMIT triangles: no scan records, use the octree");
     c->accel_request = mode;
     resolve_accel(c);
     return MCRT_OK;

@@ -445,49 +445,55 @@ MCRT_DEV Hit cast_octree(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters
 // IEEE division) as long as they are conservative; anything that can become the reported hit -
 // and every borderline case - is recomputed with the reference's exact operation sequence.
 
-// Triangle::Intersects (source/core/triangle.h:25-62) for "can this triangle beat best_t?".
-template <class P> MCRT_DEV bool tri_nearer(P big, uint32_t rec, V3 o, V3 d, float best_t, float& t_out)
+// Two triangles at a time, component-interleaved (PAIR_* layout): every float2 operation below is
+// one packed instruction whose second operand is an SGPR pair straight out of the scalar load.
+typedef float F2 __attribute__((ext_vector_type(2)));
+typedef uint32_t U8 __attribute__((ext_vector_type(8)));
+typedef uint32_t U16 __attribute__((ext_vector_type(16)));
+
+MCRT_DEV F2 f2(uint32_t a, uint32_t b) { F2 r; r.x = __uint_as_float(a); r.y = __uint_as_float(b); return r; }
+MCRT_DEV F2 dot2(F2 ax, F2 ay, F2 az, F2 bx, F2 by, F2 bz)
 {
-    const TriRec tr = load_tri(big, rec);
-    const V3 v0 = tr.v0, edge1 = tr.e1, edge2 = tr.e2;
-    const V3 h = cross(d, edge2);
-    const float a = dot(edge1, h);
-    const V3 s = o - v0;
-    const float x = dot(s, h);
-    const V3 q = cross(s, edge1);
-    const float y = dot(d, q);
-    const float z = dot(edge2, q);
-    // approximate f: relative error of u', v', t' below 4e-7
+    F2 tx = ax * bx, ty = ay * by, tz = az * bz;
+    return tx + ty + tz;
+}
+
+// The exact tail of Triangle::Intersects (source/core/triangle.h:44-61) from its exactly computed
+// intermediates a = dot(edge1,h), x = dot(s,h), y = dot(d,q), z = dot(edge2,q).
+MCRT_DEV bool tri_exact_tail(float a, float x, float y, float z, float best_t, float& t_out)
+{
+    const float f = 1.0f / a;
+    const float u = f * x;
+    if (u < 0.0f || u > 1.0f) return false;
+    const float w = f * y;
+    if (w < 0.0f || u + w > 1.0f) return false;
+    const float t = f * z;
+    if (!(t > kFltEpsilon) || !(t < best_t)) return false;
+    t_out = t;
+    return true;
+}
+
+// "can this triangle beat best_t?" decided on a reciprocal-multiply estimate (relative error of
+// u', v', t' below 4e-7) whenever the answer is a clear no.
+MCRT_DEV bool tri_maybe(float a, float x, float y, float z, float best_t)
+{
     const float fa = __builtin_amdgcn_rcpf(a);
     const float ua = fa * x, va = fa * y, ta = fa * z;
     const float m = 4.0e-6f;
-    const bool maybe = !(fabsf(a) < kFltEpsilon) && !(ua < -m) && !(ua > 1.0f + m) && !(va < -m) && !(ua + va > 1.0f + 2.0f * m) &&
-                       (ta > 0.5f * kFltEpsilon) && (ta < best_t * (1.0f + m));
-    bool hit = false;
-    if (maybe) {
-        const float f = 1.0f / a;
-        const float u = f * x;
-        if (!(u < 0.0f || u > 1.0f)) {
-            const float w = f * y;
-            if (!(w < 0.0f || u + w > 1.0f)) {
-                const float t = f * z;
-                if (t > kFltEpsilon && t < best_t) { t_out = t; hit = true; }
-            }
-        }
-    }
-    return hit;
+    return !(fabsf(a) < kFltEpsilon) && !(ua < -m) && !(ua > 1.0f + m) && !(va < -m) && !(ua + va > 1.0f + 2.0f * m) &&
+           (ta > 0.5f * kFltEpsilon) && (ta < best_t * (1.0f + m));
 }
 
 // AABB::IntersectsRay (source/core/aabb.h:49-96): decided on reciprocal-multiply slabs when the
 // outcome is clear, on the exact quotients otherwise.  `inv` = approximate 1/d per axis; `exact_only`
 // is set for rays with a denormal-range direction component (their approximate slabs overflow).
-template <class P> MCRT_DEV bool gate_hit_fast(P sm, uint32_t orec, V3 o, V3 d, V3 inv, bool exact_only)
+MCRT_DEV bool gate_hit_fast(CstPtr rec, V3 o, V3 d, V3 inv, bool exact_only)
 {
-    float tmin = -kFltMax, tmax = kFltMax;
+    const U8 b = *(const __attribute__((address_space(4))) U8*)(rec + OBJ_AABB_MIN);
+    const float mn[3] = { __uint_as_float(b.s0), __uint_as_float(b.s1), __uint_as_float(b.s2) };
+    const float mx[3] = { __uint_as_float(b.s3), __uint_as_float(b.s4), __uint_as_float(b.s5) };
     const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z }, ii[3] = { inv.x, inv.y, inv.z };
-    const U4 b0 = ld4(sm, orec + OBJ_AABB_MIN), b1 = ld4(sm, orec + OBJ_AABB_MIN + 4);
-    const float mn[3] = { __uint_as_float(b0.x), __uint_as_float(b0.y), __uint_as_float(b0.z) };
-    const float mx[3] = { __uint_as_float(b0.w), __uint_as_float(b1.x), __uint_as_float(b1.y) };
+    float tmin = -kFltMax, tmax = kFltMax;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float t1 = (mn[a] - oo[a]) * ii[a];
@@ -502,34 +508,75 @@ template <class P> MCRT_DEV bool gate_hit_fast(P sm, uint32_t orec, V3 o, V3 d, 
     const float tol = 4.0e-6f * (fabsf(tmax) + fabsf(tmin)) + 1.0e-30f;
     const bool clear_pass = diff > tol, clear_fail = diff < -tol;
     if (!exact_only && (clear_pass || clear_fail)) return clear_pass;
-    return gate_hit(sm, orec, o, d);
+    // exact: float quotients, as the reference computes them
+    tmin = -kFltMax; tmax = kFltMax;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (dd[a] != 0.0f) {
+            const float t1 = (mn[a] - oo[a]) / dd[a];
+            const float t2 = (mx[a] - oo[a]) / dd[a];
+            const float lo = (t2 < t1) ? t2 : t1;
+            const float hi = (t1 < t2) ? t2 : t1;
+            tmin = (tmin < lo) ? lo : tmin;
+            tmax = (hi < tmax) ? hi : tmax;
+        }
+    }
+    return tmax >= tmin;
 }
 
-template <class PS, class PB, bool kCount>
-MCRT_DEV Hit cast_scan(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters& cn)
+template <bool kCount>
+MCRT_DEV Hit cast_scan(CstPtr sm, CstPtr big, const SceneView& v, V3 o, V3 d, Counters& cn)
 {
     Hit best; best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax;
     if (kCount) cn.rays++;
     const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     const float tiny = 1.0e-20f;
     const bool exact_only = (d.x != 0.0f && fabsf(d.x) < tiny) || (d.y != 0.0f && fabsf(d.y) < tiny) || (d.z != 0.0f && fabsf(d.z) < tiny);
-    for (uint32_t i = 0; i < v.nobj; ++i) {
-        const uint32_t orec = v.off_obj + i * OBJ_STRIDE;
-        const uint32_t kind = sm[orec + OBJ_KIND];
-        if (kind == MCRT_OBJECT_SPHERE) {
-            float t;
+    CstPtr rec = sm + v.off_obj;
+    for (uint32_t i = 0; i < v.nobj; ++i, rec += OBJ_STRIDE) {
+        const U8 head = *(const __attribute__((address_space(4))) U8*)rec;   // kind, first_tri, tri_count, first_prim, radius, pos
+        if (head.s0 == MCRT_OBJECT_SPHERE) {
+            // SphereObject::Intersects, source/objects/sphere.h:16-52
             if (kCount) cn.spheres++;
-            if (sphere_hit(sm, orec, o, d, t) && t < best.t) { best.obj = i; best.elem = 0; best.t = t; }
+            const float radius = __uint_as_float(head.s4);
+            if (!(radius < kFltEpsilon)) {
+                const float radiusSq = radius * radius;
+                const V3 L = mk(__uint_as_float(head.s5), __uint_as_float(head.s6), __uint_as_float(head.s7)) - o;
+                const float tca = dot(L, d);
+                const float distanceSq = dot(L, L) - tca * tca;
+                if (!(tca < 0) && !(distanceSq > radiusSq)) {
+                    const float thc = sqrtf(radiusSq - distanceSq);
+                    float t0 = tca - thc, t1 = tca + thc;
+                    if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
+                    if (t0 < 0) t0 = t1;
+                    if (!(t0 < 0) && t0 < best.t) { best.obj = i; best.elem = 0; best.t = t0; }
+                }
+            }
         } else {
             if (kCount) cn.gates++;
-            const bool pass = gate_hit_fast(sm, orec, o, d, inv, exact_only);
+            const bool pass = gate_hit_fast(rec, o, d, inv, exact_only);
             if (__ballot(pass) == 0ull) continue;             // nobody in the wave needs this mesh
-            const uint32_t first = sm[orec + OBJ_FIRST_TRI], count = sm[orec + OBJ_TRI_COUNT];
-            for (uint32_t k = 0; k < count; ++k) {
+            const uint32_t count = head.s2;
+            CstPtr pr = big + v.off_pair + (size_t)rec[OBJ_FIRST_PAIR] * PAIR_STRIDE;
+            for (uint32_t k = 0; k < count; k += 2, pr += PAIR_STRIDE) {
                 if (pass) {
+                    const U16 w0 = *(const __attribute__((address_space(4))) U16*)pr;
+                    const U4 w1 = *(const __attribute__((address_space(4))) U4*)(pr + 16);
+                    const F2 v0x = f2(w0.s0, w0.s1), v0y = f2(w0.s2, w0.s3), v0z = f2(w0.s4, w0.s5);
+                    const F2 e1x = f2(w0.s6, w0.s7), e1y = f2(w0.s8, w0.s9), e1z = f2(w0.sa, w0.sb);
+                    const F2 e2x = f2(w0.sc, w0.sd), e2y = f2(w0.se, w0.sf), e2z = f2(w1.x, w1.y);
+                    // Triangle::Intersects, source/core/triangle.h:31-60, both triangles at once
+                    const F2 hx = d.y * e2z - e2y * d.z, hy = d.z * e2x - e2z * d.x, hz = d.x * e2y - e2x * d.y;   // cross(d, edge2)
+                    const F2 a = dot2(e1x, e1y, e1z, hx, hy, hz);
+                    const F2 sx = o.x - v0x, sy = o.y - v0y, sz = o.z - v0z;
+                    const F2 x = dot2(sx, sy, sz, hx, hy, hz);
+                    const F2 qx = sy * e1z - e1y * sz, qy = sz * e1x - e1z * sx, qz = sx * e1y - e1x * sy;          // cross(s, edge1)
+                    const F2 y = dot2(F2(d.x), F2(d.y), F2(d.z), qx, qy, qz);
+                    const F2 z = dot2(e2x, e2y, e2z, qx, qy, qz);
                     float t;
-                    if (kCount) cn.tris++;
-                    if (tri_nearer(big, v.off_tri + (first + k) * TRI_STRIDE, o, d, best.t, t)) { best.obj = i; best.elem = k; best.t = t; }
+                    if (kCount) cn.tris += (k + 1 < count) ? 2u : 1u;
+                    if (tri_maybe(a.x, x.x, y.x, z.x, best.t) && tri_exact_tail(a.x, x.x, y.x, z.x, best.t, t)) { best.obj = i; best.elem = k; best.t = t; }
+                    if (tri_maybe(a.y, x.y, y.y, z.y, best.t) && tri_exact_tail(a.y, x.y, y.y, z.y, best.t, t)) { best.obj = i; best.elem = k + 1; best.t = t; }
                 }
             }
         }
@@ -538,14 +585,22 @@ MCRT_DEV Hit cast_scan(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters& 
     return best;
 }
 
+template <int kAccel, class PS, class PB, bool kCount> struct Caster {
+    static MCRT_DEV Hit run(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters& cn)
+    {
+        if (kAccel == MCRT_ACCEL_BRUTE) return cast_brute<PS, PB, kCount>(sm, big, v, o, d, cn);
+        return cast_octree<PS, PB, kCount>(sm, big, v, o, d, cn);
+    }
+};
+template <bool kCount> struct Caster<MCRT_ACCEL_SCAN, CstPtr, CstPtr, kCount> {
+    static MCRT_DEV Hit run(CstPtr sm, CstPtr big, const SceneView& v, V3 o, V3 d, Counters& cn) { return cast_scan<kCount>(sm, big, v, o, d, cn); }
+};
+
 template <int kAccel, class PS, class PB, bool kCount>
 MCRT_DEV Hit cast(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters& cn)
 {
-    if (kAccel == MCRT_ACCEL_BRUTE) return cast_brute<PS, PB, kCount>(sm, big, v, o, d, cn);
-    if (kAccel == MCRT_ACCEL_SCAN) return cast_scan<PS, PB, kCount>(sm, big, v, o, d, cn);
-    return cast_octree<PS, PB, kCount>(sm, big, v, o, d, cn);
+    return Caster<kAccel, PS, PB, kCount>::run(sm, big, v, o, d, cn);
 }
-
 // --------------------------------------------------------------- materials
 // Material::BRDF, source/core/material.h:24-53
 template <class PS> MCRT_DEV double brdf(PS sm, uint32_t orec, V3 incident, V3 reflection, V3 normal)

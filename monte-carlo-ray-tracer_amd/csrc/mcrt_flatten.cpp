@@ -360,6 +360,17 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
     v.off_prim_obj = uint32_t(off);  off += nprim;
     off = (off + 3u) & ~uint64_t(3); // triangle records 16-byte aligned
     v.off_tri = uint32_t(off);       off += uint64_t(sc->triangle_count) * TRI_STRIDE;
+    // triangle-pair records for the scan path: only built for scenes it can be chosen for
+    std::vector<uint32_t> first_pair(nobj, 0);
+    uint64_t npair = 0;
+    const bool want_pairs = sc->triangle_count <= MCRT_SCAN_PAIR_LIMIT;
+    v.has_pairs = want_pairs ? 1u : 0u;
+    if (want_pairs)
+        for (uint32_t i = 0; i < nobj; ++i) {
+            first_pair[i] = uint32_t(npair);
+            if (sc->objects[i].kind != MCRT_OBJECT_SPHERE) npair += (sc->objects[i].triangle_count + 1u) / 2u;
+        }
+    v.off_pair = uint32_t(off);      off += npair * PAIR_STRIDE;
     if (off >= 0xFFFFFFF0ull) { err = "scene image exceeds 16 GiB of words"; return MCRT_ERR_LIMIT; }
     v.big_words = uint32_t(off);
     out.big_img.assign(v.big_words, 0u);
@@ -383,6 +394,20 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
             w[TRI_N + a] = fbits(tr.normal[a]);
         }
     }
+    if (want_pairs)
+        for (uint32_t i = 0; i < nobj; ++i) {
+            const mcrt_object& o = sc->objects[i];
+            out.small_img[v.off_obj + size_t(i) * OBJ_STRIDE + OBJ_FIRST_PAIR] = first_pair[i];
+            if (o.kind == MCRT_OBJECT_SPHERE) continue;
+            for (uint32_t j = 0; j * 2 < o.triangle_count; ++j) {
+                const uint32_t ta = o.first_triangle + 2 * j;
+                const uint32_t tb = (2 * j + 1 < o.triangle_count) ? ta + 1 : ta;
+                const uint32_t* ra = out.big_img.data() + v.off_tri + size_t(ta) * TRI_STRIDE;
+                const uint32_t* rb = out.big_img.data() + v.off_tri + size_t(tb) * TRI_STRIDE;
+                uint32_t* w = out.big_img.data() + v.off_pair + size_t(first_pair[i] + j) * PAIR_STRIDE;
+                for (uint32_t k = 0; k < 9; ++k) { w[2 * k] = ra[k]; w[2 * k + 1] = rb[k]; }   // v0, e1, e2 are words 0..8 of a record
+            }
+        }
     return MCRT_OK;
 }
 

@@ -34,6 +34,7 @@ enum : uint32_t {
     OBJ_ALBEDO = 22,
     OBJ_ROUGHNESS = 23,
     OBJ_IOR = 24,
+    OBJ_FIRST_PAIR = 25, // index of this mesh's first triangle-pair record (scan path)
     OBJ_COLOR = 26,      // 3 doubles (8-byte aligned: stride and offset are even)
     OBJ_EMISSION = 32,   // 3 doubles
     OBJ_STRIDE = 40
@@ -43,6 +44,13 @@ enum : uint32_t {
 // v0, edge1 = v1 - v0, edge2 = v2 - v0 (the two subtractions of
 // source/core/triangle.h:31-32 done once at upload: same floats), face normal.
 enum : uint32_t { TRI_V0 = 0, TRI_E1 = 3, TRI_E2 = 6, TRI_N = 9, TRI_STRIDE = 12 };
+
+// ---- triangle-pair record (BIG image, scan path), PAIR_STRIDE words each, 16-byte aligned.
+// Triangles 2j and 2j+1 of a mesh interleaved component by component -
+// v0x[a,b] v0y[a,b] v0z[a,b] e1x[a,b] ... e2z[a,b] - so that one scalar load brings SGPR pairs
+// that feed packed (2-wide) float instructions directly.  An odd last triangle is paired with a
+// copy of itself (a repeated test can never win the strict `<`).
+enum : uint32_t { PAIR_V0 = 0, PAIR_E1 = 6, PAIR_E2 = 12, PAIR_STRIDE = 20 };
 
 // ---- octree node arrays (BIG image), SoA: array k lives at off_node + k*node_count
 enum : uint32_t {
@@ -66,7 +74,8 @@ struct SceneView {
     uint32_t small_words, big_words;
     uint32_t nobj, nlights, ntri, nprim, nnode;
     uint32_t off_obj, off_lights, off_bg;            // into SMALL
-    uint32_t off_node, off_refs, off_prim_obj, off_tri;  // into BIG
+    uint32_t off_node, off_refs, off_prim_obj, off_tri, off_pair;  // into BIG
+    uint32_t has_pairs;          // triangle-pair records present (scan path usable)
 };
 
 } // namespace mcrt
