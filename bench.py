@@ -91,15 +91,16 @@ def main():
     be.set_accel({"auto": pkg.ACCEL_AUTO, "octree": pkg.ACCEL_OCTREE, "scan": pkg.ACCEL_SCAN, "brute": pkg.ACCEL_BRUTE}[args.accel])
     accum = torch.zeros(height * width * 3, dtype=torch.float64, device="cuda")
     be.bind_accumulator(accum.data_ptr())
-    first_sample = rank * spp                     # global sample indices of this rank
+    from mcrt_amd import sharding
+
+    first_sample, _ = sharding.rank_sample_range(rank, world, spp)     # global sample indices of this rank
 
     def step():
         be.clear()
         be.render(first_sample, spp, DEPTH, SEED)
-        if dist is not None:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)      # RCCL over xGMI: one collective per pass
+        sharding.reduce_accumulator(accum, dist, dst=0)          # RCCL over xGMI: one collective per pass
         if rank == 0:
-            be.resolve(pkg.TONEMAP_REINHARD, spp * world, want_mean=False)
+            be.resolve(pkg.TONEMAP_REINHARD, sharding.total_spp(world, spp), want_mean=False)
 
     def fence():
         if dist is not None:

@@ -195,6 +195,16 @@ int mcrt_trace_samples(mcrt_ctx* ctx, uint64_t n, const uint32_t* pixels,
                        const uint32_t* samples, uint64_t seed, uint32_t max_depth,
                        double* out_radiance);
 
+/* Scene::TraceRay(ray, uniformGenerator, traceDepth, importance),
+ * source/scene.cpp:94-234 (signature source/scene.h:50), for n explicit rays.
+ * rng_states holds n*2 uint64: the xorshift128+ state of each ray's generator
+ * on entry and, like the reference's by-reference generator, the advanced
+ * state on return.  importance: n*3 doubles or NULL for (1,1,1).
+ * out = n*3 doubles.  Host buffers. */
+int mcrt_trace_rays(mcrt_ctx* ctx, uint64_t n, const float* origins, const float* dirs,
+                    uint64_t* rng_states, uint32_t max_depth, const double* importance,
+                    double* out_radiance);
+
 /* Scene::TraceUnlit, source/scene.cpp:82-92, through pixel centres
  * (source/main.cpp:126).  out = width*height*3 doubles. */
 int mcrt_render_unlit(mcrt_ctx* ctx, double* out_color);

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(HERE, "libmcrt_hip.so")
 # every symbol include/mcrt.h declares
 ABI_SYMBOLS = (
     "mcrt_create", "mcrt_destroy", "mcrt_last_error", "mcrt_set_stream", "mcrt_upload_scene", "mcrt_set_camera", "mcrt_set_accel",
-    "mcrt_camera_rays", "mcrt_intersect", "mcrt_intersect_device", "mcrt_trace_samples", "mcrt_render_unlit", "mcrt_rng_seed",
+    "mcrt_camera_rays", "mcrt_intersect", "mcrt_intersect_device", "mcrt_trace_samples", "mcrt_trace_rays", "mcrt_render_unlit", "mcrt_rng_seed",
     "mcrt_clear", "mcrt_bind_accumulator", "mcrt_accumulator", "mcrt_render", "mcrt_last_render_ms", "mcrt_resolve",
     "mcrt_read_accumulator", "mcrt_synchronize", "mcrt_octree_info_get", "mcrt_octree_download", "mcrt_set_counting", "mcrt_counters",
     "mcrt_camera_look_at", "mcrt_scene_image_create", "mcrt_scene_image_destroy", "mcrt_scene_image_info", "mcrt_scene_image_octree",
@@ -185,6 +185,15 @@ class Backend:
         out = np.zeros((len(px), 3), np.float64)
         self._ck(self.lib.mcrt_trace_samples(self.ctx, C.c_uint64(len(px)), _ptr(px, C.c_uint32), _ptr(sm, C.c_uint32), C.c_uint64(seed), C.c_uint32(max_depth), _ptr(out, C.c_double)))
         return out
+
+    def trace_rays(self, origins, dirs, states, max_depth, importance=None):
+        """Scene::TraceRay on explicit rays; returns (radiance, advanced generator states)."""
+        o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)
+        st = np.array(states, dtype=np.uint64).reshape(-1, 2).copy()
+        imp = None if importance is None else np.ascontiguousarray(importance, np.float64).reshape(-1, 3)
+        out = np.zeros((len(o), 3), np.float64)
+        self._ck(self.lib.mcrt_trace_rays(self.ctx, C.c_uint64(len(o)), _ptr(o, C.c_float), _ptr(d, C.c_float), _ptr(st, C.c_uint64), C.c_uint32(max_depth), _ptr(imp, C.c_double) if imp is not None else None, _ptr(out, C.c_double)))
+        return out, st
 
     def render_unlit(self):
         out = np.zeros((self.height, self.width, 3), np.float64)

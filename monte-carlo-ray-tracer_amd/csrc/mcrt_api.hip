@@ -102,13 +102,23 @@ struct RenderCounters { uint32_t samples, trace_calls, splits; };
 
 enum : uint32_t { ST_NEW = 0, ST_TRACE = 1, ST_SHADOW = 2, ST_DONE = 3 };
 
+// Explicit start of a TraceRay call (mcrt_trace_rays): ray, generator state and importance come from
+// the caller instead of the camera / counter seed; the advanced generator state is written back.
+struct ExplicitStart {
+    const float* o;
+    const float* d;
+    uint64_t* state;
+    const double* importance;   // may be null: (1,1,1)
+};
+
 // One lane: samples [s_begin, s_begin + s_count) of `pixel`.  Returns the sum of the finite
 // samples in sample order (keep_nonfinite: return the raw value, used by the parity path with
 // s_count == 1) and the number dropped.
 template <class PS, class PB, int kAccel, bool kCount>
 __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, const CameraDev& cam, uint32_t pixel, uint32_t s_begin,
                                            uint32_t s_count, uint64_t seed, uint32_t max_depth, const PendStack& pend,
-                                           bool keep_nonfinite, D3& sum, uint32_t& dropped, Counters& cn, RenderCounters& rc)
+                                           bool keep_nonfinite, D3& sum, uint32_t& dropped, Counters& cn, RenderCounters& rc,
+                                           const ExplicitStart* ex = nullptr)
 {
     sum = dmk(0.0, 0.0, 0.0);
     dropped = 0;
@@ -129,13 +139,20 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
     while (state != ST_DONE) {
         if (state == ST_NEW) {
             // one iteration of the spp loop, source/main.cpp:122-139
-            uint64_t a, b;
-            sample_seed(seed, pixel, s_begin + k, a, b);
-            g.s0 = a; g.s1 = b;
-            float sx = rng_float(g);
-            float sy = rng_float(g);
-            camera_ray(cam, (float)px + sx, (float)py + sy, ro, rd);
             imp = dmk(1.0, 1.0, 1.0);
+            if (ex) {
+                g.s0 = ex->state[0]; g.s1 = ex->state[1];
+                ro = mk(ex->o[0], ex->o[1], ex->o[2]);
+                rd = mk(ex->d[0], ex->d[1], ex->d[2]);
+                if (ex->importance) imp = dmk(ex->importance[0], ex->importance[1], ex->importance[2]);
+            } else {
+                uint64_t a, b;
+                sample_seed(seed, pixel, s_begin + k, a, b);
+                g.s0 = a; g.s1 = b;
+                float sx = rng_float(g);
+                float sy = rng_float(g);
+                camera_ray(cam, (float)px + sx, (float)py + sy, ro, rd);
+            }
             L = dmk(0.0, 0.0, 0.0);
             depth = max_depth;
             npend = 0;
@@ -281,6 +298,7 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
                 const bool fin = isfinite(L.x) && isfinite(L.y) && isfinite(L.z);
                 if (fin || keep_nonfinite) sum = sum + L;
                 else dropped += 1;
+                if (ex) { ex->state[0] = g.s0; ex->state[1] = g.s1; }
                 k += 1;
                 state = (k < s_count) ? ST_NEW : ST_DONE;
             }
@@ -313,7 +331,7 @@ __device__ __forceinline__ void flush_counters(unsigned long long* out, const Co
 }
 
 template <bool kBigLds, int kAccel, bool kCount>
-__global__ __launch_bounds__(kBlock) void k_render(const RenderArgs a)
+__global__ __launch_bounds__(kBlock, 4) void k_render(const RenderArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     typedef SceneMem<kBigLds, kAccel> Mem;
@@ -364,6 +382,11 @@ struct ListArgs {
     uint64_t n;
     uint32_t max_depth;
     uint64_t seed;
+    // explicit rays (mcrt_trace_rays) when ray_o != null
+    const float* ray_o;
+    const float* ray_d;
+    uint64_t* ray_state;
+    const double* ray_importance;
 };
 
 template <bool kBigLds, int kAccel, bool kCount>
@@ -382,6 +405,13 @@ __global__ __launch_bounds__(kBlock) void k_trace_list(const ListArgs a)
     RenderCounters rc = { 0, 0, 0 };
     for (uint64_t i = pend.lane; i < a.n; i += pend.lanes) {
         D3 sum; uint32_t dropped;
+        if (a.ray_o) {
+            ExplicitStart ex;
+            ex.o = a.ray_o + 3 * i; ex.d = a.ray_d + 3 * i; ex.state = a.ray_state + 2 * i;
+            ex.importance = a.ray_importance ? a.ray_importance + 3 * i : nullptr;
+            trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, 0u, 0u, 1u, a.seed, a.max_depth, pend, true,
+                                                                          sum, dropped, cn, rc, &ex);
+        } else
         trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, a.pixels[i], a.samples[i], 1u, a.seed,
                                                                           a.max_depth, pend, true, sum, dropped, cn, rc);
         a.out[3 * i] = sum.x; a.out[3 * i + 1] = sum.y; a.out[3 * i + 2] = sum.z;
@@ -865,9 +895,45 @@ int mcrt_trace_samples(mcrt_ctx* c, uint64_t n, const uint32_t* pixels, const ui
     ListArgs a;
     a.view = c->view; a.cam = c->cam; a.pixels = dp.p; a.samples = ds.p; a.out = dout.p; a.counters = c->d_counters; a.pend = c->d_pend;
     a.n = n; a.max_depth = max_depth; a.seed = seed;
+    a.ray_o = nullptr; a.ray_d = nullptr; a.ray_state = nullptr; a.ray_importance = nullptr;
     rc = launch_list(c, a);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(out, dout.p, n * 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+
+int mcrt_trace_rays(mcrt_ctx* c, uint64_t n, const float* origins, const float* dirs, uint64_t* rng_states, uint32_t max_depth,
+                    const double* importance, double* out)
+{
+    int rc = need_scene(c, false);
+    if (rc) return rc;
+    if (n == 0) return MCRT_OK;
+    if (!origins || !dirs || !rng_states || !out) return fail(c, MCRT_ERR_INVALID, "null buffer");
+    if (max_depth > kMaxDepthLimit) return fail(c, MCRT_ERR_LIMIT, "max_depth above 256");
+    rc = ensure_pend(c, max_depth);
+    if (rc) return rc;
+    DevBuf<float> dor, ddi;
+    DevBuf<uint64_t> dst;
+    DevBuf<double> dimp, dout;
+    HIP_TRY(c, hipMalloc(&dor.p, n * 12)); HIP_TRY(c, hipMalloc(&ddi.p, n * 12)); HIP_TRY(c, hipMalloc(&dst.p, n * 16));
+    HIP_TRY(c, hipMalloc(&dout.p, n * 24));
+    HIP_TRY(c, hipMemcpyAsync(dor.p, origins, n * 12, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(ddi.p, dirs, n * 12, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dst.p, rng_states, n * 16, hipMemcpyHostToDevice, c->stream));
+    if (importance) {
+        HIP_TRY(c, hipMalloc(&dimp.p, n * 24));
+        HIP_TRY(c, hipMemcpyAsync(dimp.p, importance, n * 24, hipMemcpyHostToDevice, c->stream));
+    }
+    if (c->counting) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    ListArgs a;
+    a.view = c->view; a.cam = c->cam; a.pixels = nullptr; a.samples = nullptr; a.out = dout.p; a.counters = c->d_counters; a.pend = c->d_pend;
+    a.n = n; a.max_depth = max_depth; a.seed = 0;
+    a.ray_o = dor.p; a.ray_d = ddi.p; a.ray_state = dst.p; a.ray_importance = dimp.p;
+    rc = launch_list(c, a);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out, dout.p, n * 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(rng_states, dst.p, n * 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MCRT_OK;
 }

@@ -1,0 +1,547 @@
+// mcrt_scene.cpp - host-side scene API (see mcrt_scene.hpp).  Scene
+// construction reproduces the reference's float arithmetic so that the
+// flattened geometry is bit-identical to what its own classes hold; ray
+// arithmetic lives in libmcrt_hip.so.  Build with -ffp-contract=off.
+#include "mcrt_scene.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <random>
+#include <sstream>
+
+// ------------------------------------------------------------------ geometry
+// AABB::Encapsulate, source/core/aabb.h:98-107
+void AABB::Encapsulate(const vec3& p)
+{
+    min.x = std::min(min.x, p.x); min.y = std::min(min.y, p.y); min.z = std::min(min.z, p.z);
+    max.x = std::max(max.x, p.x); max.y = std::max(max.y, p.y); max.z = std::max(max.z, p.z);
+}
+
+// Triangle ctor, source/core/triangle.h:17-23
+Triangle::Triangle(const vec3& v0, const vec3& v1, const vec3& v2) : vertex0(v0), vertex1(v1), vertex2(v2)
+{
+    normal = normalize(cross(v1 - v0, v2 - v0));
+}
+
+// source/core/randomization.cpp:8-13
+UniformRandomGenerator::UniformRandomGenerator()
+{
+    std::random_device rd;
+    xorseed[0] = (uint64_t(rd()) << 32) ^ (rd());
+    xorseed[1] = (uint64_t(rd()) << 32) ^ (rd());
+}
+UniformRandomGenerator UniformRandomGenerator::ForSample(uint64_t seed, uint32_t pixel, uint32_t sample)
+{
+    uint64_t st[2];
+    mcrt_rng_seed(seed, pixel, sample, st);
+    return UniformRandomGenerator(st[0], st[1]);
+}
+
+// TriangleMesh::AddQuad, source/objects/mesh.cpp:49-53
+void TriangleMesh::AddQuad(vec3 p1, vec3 p2, vec3 p3, vec3 p4)
+{
+    triangles.push_back(Triangle{ p1, p2, p3 });
+    triangles.push_back(Triangle{ p3, p4, p1 });
+}
+
+// TriangleMesh::UpdateAABB, source/objects/mesh.cpp:55-68: starts from the degenerate box at `position`
+void TriangleMesh::UpdateAABB()
+{
+    if (triangles.empty()) return;
+    aabb = AABB(position, vec3{ 0.0f });
+    for (const Triangle& t : triangles) {
+        aabb.Encapsulate(t.vertex0);
+        aabb.Encapsulate(t.vertex1);
+        aabb.Encapsulate(t.vertex2);
+    }
+}
+
+// Replaces TriangleMesh::LoadMesh (source/objects/mesh.cpp:70-105), which ignores the face indices
+// (SURVEY.md 0.4).  Reads `v` and `f` records; faces are fan-triangulated (a,b,c),(a,c,d),... in file
+// order; vertices are offset by `position` as the reference does.  Prints and returns false on error.
+bool TriangleMesh::LoadMesh(std::string path)
+{
+    std::ifstream in(path);
+    if (!in) {
+        std::printf("Failed to load mesh from path: %s\r\n", path.c_str());
+        return false;
+    }
+    std::vector<vec3> verts;
+    std::string line;
+    size_t before = triangles.size();
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        std::string tag;
+        ls >> tag;
+        if (tag == "v") {
+            float x, y, z;
+            if (ls >> x >> y >> z) verts.push_back(vec3(x, y, z));
+        } else if (tag == "f") {
+            std::vector<long> idx;
+            std::string tok;
+            while (ls >> tok) {
+                long i = std::strtol(tok.c_str(), nullptr, 10);        // "v", "v/vt", "v/vt/vn", "v//vn"
+                if (i < 0) i = long(verts.size()) + i + 1;               // relative indices
+                if (i < 1 || i > long(verts.size())) { idx.clear(); break; }
+                idx.push_back(i - 1);
+            }
+            for (size_t k = 1; k + 1 < idx.size(); ++k)
+                triangles.push_back(Triangle{ verts[size_t(idx[0])] + position, verts[size_t(idx[k])] + position, verts[size_t(idx[k + 1])] + position });
+        }
+    }
+    std::printf("Loaded obj: %s (%zu triangles)\r\n", path.c_str(), triangles.size() - before);
+    return triangles.size() > before;
+}
+
+// Box::SetGeometry, source/objects/box.h:14-55
+void Box::SetGeometry(vec3 basePosition, vec3 upVector, vec3 sideVector, float width, float depth, float height)
+{
+    position = basePosition;
+    upVector = normalize(upVector);
+    sideVector = normalize(sideVector);
+    const vec3 localZ = cross(sideVector, upVector);
+    const vec3 localX = cross(upVector, localZ);
+    const float halfWidth = width / 2.0f, halfDepth = depth / 2.0f;
+
+    vec3 base[4] = {
+        localX * halfWidth + localZ * halfDepth,
+        localX * halfWidth - localZ * halfDepth,
+        localX * halfWidth * -1.0f - localZ * halfDepth,
+        localX * halfWidth * -1.0f + localZ * halfDepth,
+    };
+    vec3 top[4];
+    for (int i = 0; i < 4; ++i) top[i] = base[i] + upVector * height;
+    for (int i = 0; i < 4; ++i) base[i] += basePosition;
+    for (int i = 0; i < 4; ++i) top[i] += basePosition;
+
+    AddQuad(base[3], base[2], base[1], base[0]);       // bottom
+    AddQuad(top[0], top[1], top[2], top[3]);           // top
+    for (int i = 0; i < 4; ++i) {                      // the four sides, in the reference's order
+        const int j = (i + 1) & 3;
+        AddQuad(base[i], base[j], top[j], top[i]);
+    }
+}
+
+// Light::SetGeometry, source/objects/light.h:22-43
+void Light::SetGeometry(vec3 centerPosition, vec3 lightDirection, vec3 sideDirection, vec2 quadDimensions)
+{
+    area = quadDimensions.x * quadDimensions.y;
+    normal = normalize(lightDirection);
+    position = centerPosition;
+    yVector = normalize(cross(sideDirection, normal));
+    xVector = normalize(cross(yVector, normal));
+    xVector *= quadDimensions.x / 2.0f;
+    yVector *= quadDimensions.y / 2.0f;
+    const vec3 p1 = position - xVector - yVector;
+    const vec3 p2 = position - xVector + yVector;
+    const vec3 p3 = position + xVector + yVector;
+    const vec3 p4 = position + xVector - yVector;
+    position += lightDirection * INTERSECTION_ERROR_MARGIN;
+    AddQuad(p1, p2, p3, p4);
+}
+
+// --------------------------------------------------------------- pixel buffer
+// source/core/pixelbuffer.cpp:7-23
+PixelBuffer::PixelBuffer(unsigned int width, unsigned int height) : imageWidth(width), imageHeight(height)
+{
+    dataSize = imageWidth * imageHeight * 3;
+    data.assign(dataSize, 0.0);
+    dx = 2.0 / double(imageWidth);
+    dy = 2.0 / double(imageHeight);
+    aspect = imageWidth / double(imageHeight);
+}
+ColorDbl PixelBuffer::GetPixelColor(unsigned int x, unsigned int y)
+{
+    const unsigned int i = PixelArrayIndex(x, y);
+    return ColorDbl(data[i], data[i + 1], data[i + 2]);
+}
+
+// source/core/camera.h:19-34
+Camera::Camera(unsigned int width, unsigned int height, float fovY) : pixels{ width, height }
+{
+    const float o[3] = { 0, 0, 0 }, t[3] = { 0, 0, -1 }, u[3] = { 0, 1, 0 };
+    mcrt_camera_look_at(width, height, fovY, o, t, u, &view);
+    fov = fovY;
+}
+void Camera::SetView(vec3 position, vec3 lookAtPosition, vec3 cameraUp)
+{
+    const float p[3] = { position.x, position.y, position.z }, t[3] = { lookAtPosition.x, lookAtPosition.y, lookAtPosition.z };
+    const float u[3] = { cameraUp.x, cameraUp.y, cameraUp.z };
+    mcrt_camera_look_at(view.width, view.height, fov, p, t, u, &view);
+}
+
+void Octree::PrintDebug() const
+{
+    std::printf("octree: %u nodes, %u primitive references, depth %u, %s\r\n", nodeCount, primitiveRefs, depth,
+                ldsResident ? "LDS resident" : "read through L2");
+}
+
+// ---------------------------------------------------------------------- scene
+Scene::~Scene()
+{
+    for (Object* o : objects) delete o;       // lights are aliases, source/scene.cpp:32-36
+    if (ctx) mcrt_destroy(ctx);
+}
+
+bool Scene::Fail(const char* what) const
+{
+    std::fprintf(stderr, "mcrt: %s: %s\n", what, mcrt_last_error(ctx));
+    return false;
+}
+
+bool Scene::EnsureContext()
+{
+    if (ctx) return true;
+    if (mcrt_create(device, &ctx) != MCRT_OK) {
+        ctx = nullptr;
+        return Fail("no GPU context (this backend has no CPU path)");
+    }
+    return true;
+}
+
+bool Scene::Flatten(mcrt_scene_desc& out)
+{
+    // light cache, source/scene.cpp:41-49
+    lights.clear();
+    for (Object* o : objects) {
+        const Material& m = o->material;
+        if (m.emission.r > 0.0 || m.emission.g > 0.0 || m.emission.b > 0.0) lights.push_back(o);
+    }
+    for (Object* o : objects) o->UpdateAABB();      // source/scene.cpp:52-55
+
+    flatObjects.clear();
+    flatTriangles.clear();
+    octree.aabb.Reset();
+    for (Object* o : objects) {
+        octree.aabb.Encapsulate(o->aabb);           // Octree::Fill root box, octree.h:83-86
+        mcrt_object d;
+        std::memset(&d, 0, sizeof d);
+        d.kind = o->Kind();
+        d.position[0] = o->position.x; d.position[1] = o->position.y; d.position[2] = o->position.z;
+        d.aabb_min[0] = o->aabb.min.x; d.aabb_min[1] = o->aabb.min.y; d.aabb_min[2] = o->aabb.min.z;
+        d.aabb_max[0] = o->aabb.max.x; d.aabb_max[1] = o->aabb.max.y; d.aabb_max[2] = o->aabb.max.z;
+        const Material& m = o->material;
+        d.material.color[0] = m.color.r; d.material.color[1] = m.color.g; d.material.color[2] = m.color.b;
+        d.material.emission[0] = m.emission.r; d.material.emission[1] = m.emission.g; d.material.emission[2] = m.emission.b;
+        d.material.surface = int32_t(m.type);
+        d.material.diffuse = int32_t(m.diffuse);
+        d.material.albedo = m.albedo; d.material.roughness = m.roughness; d.material.refractive_index = m.refractiveIndex;
+        if (SphereObject* s = dynamic_cast<SphereObject*>(o)) d.radius = s->radius;
+        if (TriangleMesh* mesh = dynamic_cast<TriangleMesh*>(o)) {
+            d.first_triangle = uint32_t(flatTriangles.size());
+            d.triangle_count = uint32_t(mesh->triangles.size());
+            for (const Triangle& t : mesh->triangles) {
+                mcrt_triangle ft;
+                const vec3* src[4] = { &t.vertex0, &t.vertex1, &t.vertex2, &t.normal };
+                float* dst[4] = { ft.v0, ft.v1, ft.v2, ft.normal };
+                for (int k = 0; k < 4; ++k) { dst[k][0] = src[k]->x; dst[k][1] = src[k]->y; dst[k][2] = src[k]->z; }
+                flatTriangles.push_back(ft);
+            }
+            if (Light* l = dynamic_cast<Light*>(o)) {
+                d.light_x[0] = l->xVector.x; d.light_x[1] = l->xVector.y; d.light_x[2] = l->xVector.z;
+                d.light_y[0] = l->yVector.x; d.light_y[1] = l->yVector.y; d.light_y[2] = l->yVector.z;
+            }
+        }
+        flatObjects.push_back(d);
+    }
+    out.object_count = uint32_t(flatObjects.size());
+    out.triangle_count = uint32_t(flatTriangles.size());
+    out.objects = flatObjects.data();
+    out.triangles = flatTriangles.data();
+    out.background[0] = backgroundColor.r; out.background[1] = backgroundColor.g; out.background[2] = backgroundColor.b;
+    return true;
+}
+
+void Scene::PrepareForRayTracing()
+{
+    prepared = false;
+    mcrt_scene_desc desc;
+    Flatten(desc);
+    if (!EnsureContext()) return;
+    mcrt_accel_params accel = { octree.maxCount, octree.maxDepth, 0.0f };
+    if (mcrt_upload_scene(ctx, &desc, &accel) != MCRT_OK) { Fail("upload_scene"); return; }
+    mcrt_octree_info info;
+    if (mcrt_octree_info_get(ctx, &info) == MCRT_OK) {
+        octree.nodeCount = info.node_count; octree.primitiveRefs = info.prim_ref_count;
+        octree.depth = info.max_depth; octree.ldsResident = info.lds_resident != 0;
+    }
+    boundCamera = nullptr;
+    prepared = true;
+}
+
+bool Scene::IntersectRay(Ray& ray, RayIntersectionInfo& hitInfo)
+{
+    hitInfo.Reset();
+    if (!prepared) return Fail("IntersectRay before PrepareForRayTracing");
+    int32_t obj = -1; uint32_t elem = 0; float t = FLOAT_INFINITY;
+    if (mcrt_intersect(ctx, 1, &ray.origin.x, &ray.direction.x, &obj, &elem, &t) != MCRT_OK) return Fail("intersect");
+    if (obj < 0) return false;
+    hitInfo.object = objects[size_t(obj)];
+    hitInfo.elementIndex = elem;
+    hitInfo.hitDistance = t;
+    return true;
+}
+
+// source/scene.cpp:82-92
+ColorDbl Scene::TraceUnlit(Ray ray)
+{
+    RayIntersectionInfo hitInfo;
+    if (IntersectRay(ray, hitInfo)) return hitInfo.object->material.color;
+    return ColorDbl{ 0.0 };
+}
+
+ColorDbl Scene::TraceRay(Ray ray, UniformRandomGenerator& uniformGenerator, unsigned int traceDepth, ColorDbl importance)
+{
+    if (!prepared) { Fail("TraceRay before PrepareForRayTracing"); return ColorDbl{ 0.0 }; }
+    double out[3] = { 0, 0, 0 };
+    if (mcrt_trace_rays(ctx, 1, &ray.origin.x, &ray.direction.x, uniformGenerator.xorseed, traceDepth, &importance.r, out) != MCRT_OK) {
+        Fail("trace_rays");
+        return ColorDbl{ 0.0 };
+    }
+    return ColorDbl(out[0], out[1], out[2]);
+}
+
+bool Scene::Render(Camera& camera, uint32_t sampleBegin, uint32_t sampleCount, unsigned int traceDepth, uint64_t seed)
+{
+    if (!prepared) return Fail("Render before PrepareForRayTracing");
+    if (boundCamera != &camera) {
+        if (mcrt_set_camera(ctx, &camera.view) != MCRT_OK) return Fail("set_camera");
+        boundCamera = &camera;
+        camera.pixels.rays = 0;
+    }
+    if (mcrt_render(ctx, sampleBegin, sampleCount, traceDepth, seed) != MCRT_OK) return Fail("render");
+    camera.pixels.rays += sampleCount;
+    return true;
+}
+
+bool Scene::Clear(Camera& camera)
+{
+    if (boundCamera != &camera) return true;
+    camera.pixels.rays = 0;
+    return mcrt_clear(ctx) == MCRT_OK || Fail("clear");
+}
+
+bool Scene::ReadBack(Camera& camera)
+{
+    if (boundCamera != &camera) return Fail("ReadBack: camera not rendered with this scene");
+    return mcrt_read_accumulator(ctx, camera.pixels.data.data()) == MCRT_OK || Fail("read_accumulator");
+}
+
+bool Scene::Resolve(Camera& camera, int tonemap, double gamma, double exposure, std::vector<uint8_t>& bgra8)
+{
+    if (boundCamera != &camera || camera.pixels.rays == 0) return Fail("Resolve: nothing rendered with this camera");
+    bgra8.resize(size_t(camera.pixels.numPixels()) * 4);
+    return mcrt_resolve(ctx, tonemap, gamma, exposure, camera.pixels.rays, bgra8.data(), nullptr) == MCRT_OK || Fail("resolve");
+}
+
+// source/scene.cpp:236-239
+void Scene::MoveCameraToRecommendedPosition(Camera& camera)
+{
+    camera.SetView(vec3(0.0f, 0.0f, 0.0f), vec3(0.0f, 0.0f, 1.0f), vec3(0.0f, 1.0f, 0.0f));
+}
+
+// ----------------------------------------------------------- example scenes
+// HexagonScene, source/scene.cpp:242-366
+HexagonScene::HexagonScene()
+{
+    ceiling = CreateObject<TriangleMesh>();
+    floor = CreateObject<TriangleMesh>();
+    walls1 = CreateObject<TriangleMesh>();
+    walls2 = CreateObject<TriangleMesh>();
+    walls3 = CreateObject<TriangleMesh>();
+    ceiling->material.color = ColorDbl(0.2);
+    floor->material.color = ColorDbl(0.2);
+    walls1->material.color = ColorDbl(0.2, 0.01, 0.01);
+    walls2->material.color = ColorDbl(0.01, 0.2, 0.01);
+    walls3->material.color = ColorDbl(0.2);
+
+    // six ceiling corners (x, y, z); the floor mirrors them in y
+    const float cx[6] = { 0.0f, 6.0f, 6.0f, 0.0f, -6.0f, -6.0f };
+    const float cz[6] = { -3.0f, 0.0f, 10.0f, 13.0f, 10.0f, 0.0f };
+    vec3 c[6], f[6];
+    for (int i = 0; i < 6; ++i) { c[i] = vec3(cx[i], 5.0f, cz[i]); f[i] = c[i]; f[i].y *= -1.0f; }
+
+    floor->AddQuad(f[0], f[3], f[2], f[1]);
+    floor->AddQuad(f[0], f[5], f[4], f[3]);
+    ceiling->AddQuad(c[0], c[1], c[2], c[3]);
+    ceiling->AddQuad(c[3], c[4], c[5], c[0]);
+    walls1->AddQuad(f[1], f[2], c[2], c[1]);
+    walls2->AddQuad(f[0], f[1], c[1], c[0]);
+    walls3->AddQuad(f[2], f[3], c[3], c[2]);
+    walls2->AddQuad(f[4], f[5], c[5], c[4]);
+    walls3->AddQuad(f[3], f[4], c[4], c[3]);
+    walls3->AddQuad(f[5], f[0], c[0], c[5]);
+}
+
+void HexagonScene::MoveCameraToRecommendedPosition(Camera& camera)
+{
+    camera.SetView(vec3(0.0f, 0.0f, 0.0f), vec3(0.0f, 0.0f, 10.0f), vec3(0.0f, 1.0f, 0.0f));
+}
+
+void HexagonScene::AddExampleObjects(float radius)
+{
+    SphereObject* spheres[3];
+    const SurfaceType kinds[3] = { SurfaceType::Diffuse, SurfaceType::Specular, SurfaceType::Refractive };
+    const vec3 where[3] = { vec3(3.0, 2.0, 10.0f), vec3(-3.0f, 0.0, 8.0f), vec3(1.0f, -3.0, 6.0f) };
+    for (int i = 0; i < 3; ++i) {
+        spheres[i] = CreateObject<SphereObject>();
+        spheres[i]->material.type = kinds[i];
+        spheres[i]->radius = radius;
+        spheres[i]->position = where[i];
+        spheres[i]->material.color = ColorDbl(0.5);
+    }
+    Box* box = CreateObject<Box>();
+    box->SetGeometry({ 3.0, -5.0, 10.0 }, { 0.0f, 1.0f, 0.0f }, { 0.5f, 0.0f, 1.0f }, 2.0f, 2.0f, 7.0f - radius);
+    box->material.color = ColorDbl(0.01, 0.3, 0.8);
+    box->material.type = SurfaceType::Diffuse;
+    Box* box2 = CreateObject<Box>();
+    box2->SetGeometry({ -3.0, -5.0, 8.0 }, { 0.0f, 1.0f, 0.0f }, { 0.5f, 0.0f, 1.0f }, 2.0f, 2.0f, 5.0f - radius);
+    box2->material.color = ColorDbl(0.8, 0.4, 0.01);
+    box2->material.type = SurfaceType::Refractive;
+    Box* box3 = CreateObject<Box>();
+    box3->SetGeometry({ 1.0, -5.0, 6.0 }, { 0.0f, 1.0f, 0.0f }, { 0.5f, 0.0f, 1.0f }, 4.0f, 4.0f, 2.0f - radius);
+    box3->material.color = ColorDbl(0.5, 0.2, 0.8);
+    box3->material.type = SurfaceType::Diffuse;
+    spheres[2]->material.refractiveIndex = 1.52f;
+    box2->material.refractiveIndex = 1.52f;
+}
+
+namespace {
+// the two light variants shared by both example scenes, source/scene.cpp:344-366,481-503
+void AddLightAt(Scene& scene, vec3 roofCenter, vec2 dims, ColorDbl lightColor, bool usePoint)
+{
+    if (usePoint) {
+        SphereObject* pointLight = scene.CreateObject<SphereObject>();
+        pointLight->radius = 0.0f;
+        pointLight->material.color = lightColor;
+        pointLight->material.emission = lightColor;
+        pointLight->position = roofCenter;
+    } else {
+        Light* light = scene.CreateObject<Light>();
+        light->SetGeometry(roofCenter, { 0.0f, -1.0f, 0.0f }, { 1.0f, 0.0f, 0.0f }, dims);
+        light->material.color = lightColor;
+        light->material.emission = lightColor;
+    }
+}
+} // namespace
+
+void HexagonScene::AddExampleLight(ColorDbl lightColor, bool usePoint)
+{
+    AddLightAt(*this, vec3{ 0.0f, 5.0f - 0.001f, 8.0f }, vec2{ 1.0f, 1.0f }, lightColor, usePoint);
+}
+
+// CornellBoxScene, source/scene.cpp:370-503
+CornellBoxScene::CornellBoxScene(float length, float width, float height)
+{
+    halfLength = length / 2.0f;
+    halfWidth = width / 2.0f;
+    halfHeight = height / 2.0f;
+    leftWall = CreateObject<TriangleMesh>();
+    rightWall = CreateObject<TriangleMesh>();
+    whiteSegments = CreateObject<TriangleMesh>();
+    leftWall->material.color = ColorDbl(0.2, 0.01, 0.01);
+    rightWall->material.color = ColorDbl(0.01, 0.2, 0.01);
+    whiteSegments->material.color = ColorDbl(0.2);
+
+    const vec3 c1{ -halfWidth, halfHeight, halfLength }, c2{ halfWidth, halfHeight, halfLength };
+    const vec3 c3{ halfWidth, halfHeight, -halfLength }, c4{ -halfWidth, halfHeight, -halfLength };
+    vec3 f1 = c1, f2 = c2, f3 = c3, f4 = c4;
+    f1.y *= -1.0f; f2.y *= -1.0f; f3.y *= -1.0f; f4.y *= -1.0f;
+
+    leftWall->AddQuad(f2, c2, c3, f3);
+    rightWall->AddQuad(f1, f4, c4, c1);
+    whiteSegments->AddQuad(c4, c3, c2, c1);   // ceiling
+    whiteSegments->AddQuad(f4, f3, c3, c4);   // back wall
+    whiteSegments->AddQuad(f1, f2, f3, f4);   // floor
+}
+
+void CornellBoxScene::MoveCameraToRecommendedPosition(Camera& camera)
+{
+    camera.SetView(vec3(0.0f, 0.0f, halfLength), vec3(0.0f, 0.0f, 0.0f), vec3(0.0f, 1.0f, 0.0f));
+}
+
+void CornellBoxScene::AddExampleObjects(float radius)
+{
+    SphereObject* lambertianSphere = CreateObject<SphereObject>();
+    SphereObject* specularSphere = CreateObject<SphereObject>();
+    SphereObject* orenNayarSphere = CreateObject<SphereObject>();
+    SphereObject* refractionSphere = CreateObject<SphereObject>();
+    for (SphereObject* s : { lambertianSphere, specularSphere, orenNayarSphere, refractionSphere }) {
+        s->radius = radius;
+        s->material.color = ColorDbl(0.5);
+    }
+    const float widthOffset = halfWidth - radius;
+    const float depthOffset = halfLength - radius;
+    lambertianSphere->position = vec3(-widthOffset, 0.0f, -depthOffset / 2.0);
+    specularSphere->position = vec3(0, 2.0, -halfLength + specularSphere->radius);
+    orenNayarSphere->position = vec3(widthOffset, 0.0f, -depthOffset / 2.0);
+    refractionSphere->position = vec3(0, -halfHeight + refractionSphere->radius + 1.5, -2);
+
+    Box* orenNayarBox = CreateObject<Box>();
+    orenNayarBox->SetGeometry({ halfWidth - 1.5f, -halfHeight, -depthOffset / 2.0 }, { 0.0f, 1.0f, 0.0f }, { -0.5f, 0.0f, 1.0f }, 2.0f, 2.0f, halfHeight - radius);
+    orenNayarBox->material.color = ColorDbl(0.01, 0.3, 0.8);
+    Box* lambertianBox = CreateObject<Box>();
+    lambertianBox->SetGeometry({ -halfWidth + 1.5f, -halfHeight, -depthOffset / 2.0 }, { 0.0f, 1.0f, 0.0f }, { 0.5f, 0.0f, 1.0f }, 2.0f, 2.0f, halfHeight - radius);
+    lambertianBox->material.color = ColorDbl(0.8, 0.4, 0.01);
+    Box* middleBox = CreateObject<Box>();
+    middleBox->SetGeometry({ 0, -halfHeight, -3 }, { 0.0f, 1.0f, 0.0f }, { 1.0f, 0.0f, 1.0f }, 4.0f, 4.0f, halfHeight - refractionSphere->radius - 2.3f);
+    middleBox->material.color = ColorDbl(0.5, 0.2, 0.8);
+
+    orenNayarBox->material.diffuse = DiffuseType::OrenNayar;
+    orenNayarSphere->material.diffuse = DiffuseType::OrenNayar;
+    orenNayarSphere->material.roughness = 0.5f;
+    orenNayarBox->material.roughness = 0.5f;
+    specularSphere->material.type = SurfaceType::Specular;
+    refractionSphere->material.type = SurfaceType::Refractive;
+    refractionSphere->material.refractiveIndex = 1.4f;
+}
+
+void CornellBoxScene::AddExampleLight(ColorDbl lightColor, bool usePoint)
+{
+    AddLightAt(*this, vec3{ 0.0f, halfHeight - 0.001f, 0.0f }, vec2{ halfWidth / 3.0f, halfHeight / 3.0f }, lightColor, usePoint);
+}
+
+// ------------------------------------------------------------------- C shim
+// Lets tests (ctypes) build the example scenes through this layer and compare the flat description
+// with dumps of the reference's own objects.
+extern "C" {
+
+void* mcrt_host_scene_create(int which, float radius, double light_strength, int use_point_light)
+{
+    if (which == 0) {
+        CornellBoxScene* s = new CornellBoxScene(10.0f, 10.0f, 10.0f);   // source/main.cpp:237-241
+        s->backgroundColor = { 0.0, 0.0, 0.0 };
+        s->AddExampleObjects(radius);
+        s->AddExampleLight(ColorDbl{ light_strength }, use_point_light != 0);
+        return static_cast<Scene*>(s);
+    }
+    HexagonScene* s = new HexagonScene();
+    s->AddExampleObjects(radius);
+    s->AddExampleLight(ColorDbl{ light_strength }, use_point_light != 0);
+    return static_cast<Scene*>(s);
+}
+
+void mcrt_host_scene_destroy(void* scene) { delete static_cast<Scene*>(scene); }
+
+// Object added through the public API: a TriangleMesh loaded from an OBJ file.
+int mcrt_host_scene_add_obj(void* scene, const char* path, float px, float py, float pz, double grey)
+{
+    TriangleMesh* m = static_cast<Scene*>(scene)->CreateObject<TriangleMesh>();
+    m->position = vec3(px, py, pz);
+    m->material.color = ColorDbl(grey);
+    return m->LoadMesh(path) ? int(m->triangles.size()) : -1;
+}
+
+// Pointers stay valid until the next call on the same scene.
+int mcrt_host_scene_flatten(void* scene, mcrt_scene_desc* out) { return static_cast<Scene*>(scene)->Flatten(*out) ? 0 : 1; }
+
+int mcrt_host_scene_prepare(void* scene)
+{
+    Scene* s = static_cast<Scene*>(scene);
+    s->PrepareForRayTracing();
+    return s->Context() ? 0 : 1;
+}
+
+} // extern "C"

@@ -1,0 +1,252 @@
+// mcrt_scene.hpp - host-side scene description API, source-compatible with the
+// reference renderer's public classes for the render path, backed by the HIP
+// library through include/mcrt.h.
+//
+// What is mirrored (names, members, argument meaning, no-exception/return-false
+// error behaviour) and where it comes from in the reference:
+//   Material, SurfaceType, DiffuseType      source/core/material.h:8-19
+//   Ray, RayIntersectionInfo                source/core/ray.h:8-29
+//   AABB                                    source/core/aabb.h:11-28,98-113
+//   Triangle                                source/core/triangle.h:8-23
+//   UniformRandomGenerator                  source/core/randomization.h:13-50
+//   Object, SphereObject, TriangleMesh,
+//   Box, Light                              source/objects/*.h
+//   PixelBuffer, Camera                     source/core/pixelbuffer.h, camera.h
+//   Octree (Fill / maxCount / aabb)         source/accelerationstructures/octree.h:31-92
+//   Scene, CornellBoxScene, HexagonScene    source/scene.h:16-92
+//
+// What is different on purpose: the classes DESCRIBE the scene; every piece of
+// ray arithmetic (Intersects, BRDF, TraceRay recursion, hemisphere sampling)
+// runs on the GPU.  Scene::IntersectRay / TraceRay / TraceUnlit keep their
+// signatures and forward single queries to the device; the batch entry points
+// (Scene::Render, Camera::Resolve) are what a driver should call.  There is no
+// CPU fallback: without a device these calls report failure (false / black and
+// a message on stderr), as the reference reports failure with false/nullptr.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "mcrt.h"
+#include "mcrt_math.hpp"
+
+enum class SurfaceType { Diffuse, Specular, Diffuse_Specular, Refractive, COUNT };
+enum class DiffuseType { Lambertian, OrenNayar, COUNT };
+
+struct Material {
+    ColorDbl color = ColorDbl{ 1.0, 1.0, 1.0 };
+    ColorDbl emission = ColorDbl{ 0.0, 0.0, 0.0 };
+    SurfaceType type = SurfaceType::Diffuse;
+    DiffuseType diffuse = DiffuseType::Lambertian;
+    float albedo = 1.0f;
+    float roughness = 1.0f;
+    float refractiveIndex = 1.52f;
+};
+
+struct Ray {
+    vec3 origin;
+    vec3 direction;
+    Ray() = default;
+    Ray(vec3 start, vec3 dir) : origin(start), direction(dir) {}
+};
+
+class Object;
+struct RayIntersectionInfo {
+    Object* object = nullptr;
+    unsigned int elementIndex = 0;
+    float hitDistance = FLOAT_INFINITY;
+    void Reset() { object = nullptr; elementIndex = 0; hitDistance = FLOAT_INFINITY; }
+};
+
+struct AABB {
+    vec3 center, min, max;
+    AABB(vec3 centerPosition = vec3{ 0.0f }, vec3 dimensions = vec3{ 0.0f })
+        : center(centerPosition), min(centerPosition - dimensions / 2.0f), max(centerPosition + dimensions / 2.0f) {}
+    void Reset() { center = min = max = vec3{ 0.0f }; }
+    void Encapsulate(const vec3& p);
+    void Encapsulate(const AABB& other) { Encapsulate(other.min); Encapsulate(other.max); }
+};
+
+struct Triangle {
+    vec3 vertex0, vertex1, vertex2, normal;
+    Triangle(const vec3& v0, const vec3& v1, const vec3& v2);
+};
+
+// xorshift128+ state holder.  Draws happen on the device; the host object only
+// carries the 128-bit state in and out of Scene::TraceRay.
+class UniformRandomGenerator {
+public:
+    uint64_t xorseed[2] = { 0, 0 };
+    UniformRandomGenerator();                                     // std::random_device, like the reference
+    UniformRandomGenerator(uint64_t a, uint64_t b) { xorseed[0] = a; xorseed[1] = b; }
+    // state for camera sample (seed, pixel, sample): the counter mapping of mcrt_rng_seed
+    static UniformRandomGenerator ForSample(uint64_t seed, uint32_t pixel, uint32_t sample);
+};
+
+class Object {
+public:
+    vec3 position;
+    Material material;
+    float area = 1.0f;
+    AABB aabb;
+    Object() = default;
+    virtual ~Object() = default;
+    virtual bool IsLight() { return false; }
+    virtual double PDF() { return 1.0 / area; }
+    virtual void UpdateAABB() {}
+    virtual int Kind() const = 0;                                  // MCRT_OBJECT_*
+};
+
+class SphereObject : public Object {
+public:
+    float radius = 1.0f;
+    void UpdateAABB() override { aabb = AABB(position, vec3{ radius }); }   // half-size on purpose, sphere.h:71-74
+    int Kind() const override { return MCRT_OBJECT_SPHERE; }
+};
+
+class TriangleMesh : public Object {
+public:
+    std::vector<Triangle> triangles;
+    void AddQuad(vec3 p1, vec3 p2, vec3 p3, vec3 p4);              // ccw with respect to the normal
+    void UpdateAABB() override;
+    // Index-correct OBJ reader (v / f records; quads and n-gons fan-triangulated), offset by `position`.
+    bool LoadMesh(std::string path);
+    int Kind() const override { return MCRT_OBJECT_MESH; }
+};
+
+class Box : public TriangleMesh {
+public:
+    void SetGeometry(vec3 basePosition, vec3 upVector, vec3 sideVector, float width, float depth, float height);
+};
+
+class Light : public TriangleMesh {
+public:
+    vec3 normal, xVector, yVector;
+    Light(ColorDbl lightEmission = ColorDbl{ 1.0 }) { material.emission = lightEmission; }
+    void SetGeometry(vec3 centerPosition, vec3 lightDirection, vec3 sideDirection, vec2 quadDimensions);
+    bool IsLight() override { return true; }
+    int Kind() const override { return MCRT_OBJECT_LIGHT; }
+};
+
+class PixelBuffer {
+protected:
+    unsigned int dataSize = 0, imageWidth = 0, imageHeight = 0;
+    double dx = 0.0, dy = 0.0, aspect = 1.0;
+    std::vector<double> data;                                      // accumulator sums, filled by Camera::ReadBack
+    uint64_t rays = 0;                                             // samples per pixel accumulated so far
+    friend class Camera;
+    friend class Scene;
+public:
+    PixelBuffer(unsigned int width, unsigned int height);
+    int size() const { return int(dataSize); }
+    int numPixels() const { return int(imageWidth * imageHeight); }
+    int width() const { return int(imageWidth); }
+    int height() const { return int(imageHeight); }
+    double deltaX() const { return dx; }
+    double deltaY() const { return dy; }
+    double aspectRatio() const { return aspect; }
+    unsigned int PixelArrayIndex(unsigned int x, unsigned int y) { return y * imageWidth * 3 + x * 3; }
+    uint64_t GetRayCount(unsigned int) { return rays; }
+    ColorDbl GetPixelColor(unsigned int x, unsigned int y);
+};
+
+class Camera {
+protected:
+    mcrt_camera view{};
+    float fov = 90.0f;
+    friend class Scene;
+public:
+    PixelBuffer pixels;
+    Camera(unsigned int width, unsigned int height, float fovY);
+    void SetView(vec3 position, vec3 lookAtPosition, vec3 cameraUp = vec3{ 0.0f, 1.0f, 0.0f });
+    const mcrt_camera& Description() const { return view; }
+};
+
+class Scene;
+// Scene::octree: the entry point name and knobs of the reference's Octree; the structure itself is the
+// flat per-primitive octree built inside mcrt_upload_scene.
+class Octree {
+public:
+    unsigned int maxCount = 0;         // 0 = library default
+    unsigned int maxDepth = 0;
+    AABB aabb;                         // root box after Fill
+    unsigned int nodeCount = 0, primitiveRefs = 0, depth = 0;
+    bool ldsResident = false;
+    void PrintDebug() const;
+};
+
+class Scene {
+protected:
+    std::vector<Object*> objects;
+    std::vector<Object*> lights;
+    mcrt_ctx* ctx = nullptr;
+    int device = 0;
+    bool prepared = false;
+    std::vector<mcrt_object> flatObjects;
+    std::vector<mcrt_triangle> flatTriangles;
+    const Camera* boundCamera = nullptr;
+    bool EnsureContext();
+    bool Fail(const char* what) const;
+public:
+    Octree octree;
+    ColorDbl backgroundColor = { 0.0, 0.0, 0.0 };
+
+    Scene() = default;
+    virtual ~Scene();
+    Scene(const Scene&) = delete;
+    Scene& operator=(const Scene&) = delete;
+
+    template <class T> T* CreateObject()
+    {
+        T* newObject = new T();
+        objects.push_back(newObject);
+        prepared = false;
+        return newObject;
+    }
+
+    void UseDevice(int deviceId) { device = deviceId; }
+    mcrt_ctx* Context() { return EnsureContext() ? ctx : nullptr; }
+
+    // Light cache + UpdateAABB (source/scene.cpp:41-55), then flatten and upload (replaces octree.Fill, :58).
+    void PrepareForRayTracing();
+    // The flat description PrepareForRayTracing uploads (no device needed).
+    bool Flatten(mcrt_scene_desc& out);
+
+    bool IntersectRay(Ray& ray, RayIntersectionInfo& hitInfo);
+    ColorDbl TraceUnlit(Ray ray);
+    double MaxImportance(ColorDbl& importance)
+    {
+        double yz = importance.g < importance.b ? importance.b : importance.g;
+        return importance.r < yz ? yz : importance.r;
+    }
+    ColorDbl TraceRay(Ray ray, UniformRandomGenerator& uniformGenerator, unsigned int traceDepth = 5, ColorDbl importance = ColorDbl{ 1.0 });
+
+    // Batch entry points (what replaces TracePixels, source/main.cpp:169-184).
+    bool Render(Camera& camera, uint32_t sampleBegin, uint32_t sampleCount, unsigned int traceDepth, uint64_t seed);
+    bool ReadBack(Camera& camera);                                   // device accumulators -> camera.pixels
+    bool Resolve(Camera& camera, int tonemap, double gamma, double exposure, std::vector<uint8_t>& bgra8);
+    bool Clear(Camera& camera);
+
+    virtual void MoveCameraToRecommendedPosition(Camera& camera);
+};
+
+class HexagonScene : public Scene {
+protected:
+    TriangleMesh *ceiling, *floor, *walls1, *walls2, *walls3;
+public:
+    HexagonScene();
+    void MoveCameraToRecommendedPosition(Camera& camera) override;
+    void AddExampleObjects(float radius = 1.5f);
+    void AddExampleLight(ColorDbl lightColor, bool usePoint = false);
+};
+
+class CornellBoxScene : public Scene {
+protected:
+    float halfLength = 0.0f, halfWidth = 0.0f, halfHeight = 0.0f;
+    TriangleMesh *leftWall, *rightWall, *whiteSegments;
+public:
+    CornellBoxScene(float length, float width, float height);
+    void MoveCameraToRecommendedPosition(Camera& camera) override;
+    void AddExampleObjects(float radius = 1.5f);
+    void AddExampleLight(ColorDbl lightColor, bool usePoint = false);
+};

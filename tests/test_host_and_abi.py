@@ -1,0 +1,270 @@
+"""CPU-side tests: the C ABI library loads and exports what include/mcrt.h declares, the host-side
+C++ scene API reproduces the reference's scene construction, the flat octree never hides the
+nearest hit, the fixed-order trig stays within 1 ulp of libm.  No GPU, no compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SCENES
+
+PKG_DIR = os.path.join(ROOT, "monte-carlo-ray-tracer_amd")
+
+
+def test_header_symbols_are_exported(pkg):
+    header = open(os.path.join(ROOT, "include", "mcrt.h")).read()
+    declared = sorted(set(re.findall(r"\b(mcrt_[a-z_0-9]+)\s*\(", header)))
+    assert len(declared) >= 30
+    lib = pkg.load_library()
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(pkg.ABI_SYMBOLS) == declared
+
+
+def test_abi_struct_sizes_match_c(pkg, oracle):
+    # oracle.__init__ already cross-checks sizeof() of the four ABI structs compiled from mcrt.h
+    assert C.sizeof(pkg.abi.Object) == 152 and C.sizeof(pkg.abi.Triangle) == 48
+
+
+def test_no_cpu_fallback(pkg):
+    """Without a HIP device the library refuses to create a context (status 2), loudly."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.McrtError) as e:
+        pkg.Backend(0)
+    assert e.value.code == 2 and "no CPU fallback" in str(e.value)
+
+
+def test_rng_seed_mapping_agrees_everywhere(pkg, oracle, po):
+    keys = [(0, 0, 0), (0x5EED0001, 12345, 63), (2**64 - 1, 2**32 - 1, 2**32 - 1), (7, 1, 0), (7, 0, 1)]
+    for k in keys:
+        assert pkg.rng_seed(*k) == oracle.sample_seed(*k)
+    if po.Ref.available():
+        r = po.Ref()
+        for k in keys:
+            assert pkg.rng_seed(*k) == r.sample_seed(*k)
+    assert len({pkg.rng_seed(1, p, s) for p in range(64) for s in range(64)}) == 4096
+
+
+@pytest.mark.parametrize("tag", ["512", "4k", "640x480", "oblique", "hexagon"])
+def test_host_camera_matches_reference(pkg, golden, tag):
+    g = golden(f"camera_{tag}.npz")
+    a = g["args"]
+    cam = pkg.host_camera(int(a[0]), int(a[1]), float(a[2]), a[3:6], a[6:9], a[9:12])
+    assert bytes(cam) == g["camera"].tobytes()
+
+
+# ------------------------------------------------------------------ host C++ scene API
+@pytest.fixture(scope="module")
+def host():
+    path = os.path.join(PKG_DIR, "libmcrt_host.so")
+    if not os.path.exists(path):
+        pytest.skip("libmcrt_host.so not built")
+    lib = C.CDLL(path)
+    lib.mcrt_host_scene_create.restype = C.c_void_p
+    lib.mcrt_host_scene_create.argtypes = [C.c_int, C.c_float, C.c_double, C.c_int]
+    lib.mcrt_host_scene_destroy.argtypes = [C.c_void_p]
+    lib.mcrt_host_scene_flatten.argtypes = [C.c_void_p, C.c_void_p]
+    lib.mcrt_host_scene_add_obj.argtypes = [C.c_void_p, C.c_char_p, C.c_float, C.c_float, C.c_float, C.c_double]
+    return lib
+
+
+def _flatten(pkg, host, scene):
+    d = pkg.abi.SceneDesc()
+    assert host.mcrt_host_scene_flatten(scene, C.byref(d)) == 0
+    objs = np.ctypeslib.as_array(C.cast(d.objects, C.POINTER(C.c_uint8)), shape=(d.object_count * C.sizeof(pkg.abi.Object),)).copy()
+    tris = np.ctypeslib.as_array(C.cast(d.triangles, C.POINTER(C.c_uint8)), shape=(d.triangle_count * C.sizeof(pkg.abi.Triangle),)).copy()
+    return pkg.FlatScene(objs.view(pkg.abi.OBJECT_DTYPE), tris.view(pkg.abi.TRIANGLE_DTYPE), tuple(d.background))
+
+
+@pytest.mark.parametrize("which,point,name", [(0, 0, "cornell"), (0, 1, "cornell_point"), (1, 0, "hexagon")])
+def test_host_scene_builders_match_reference_dump(pkg, host, scene_of, which, point, name):
+    """CornellBoxScene / HexagonScene / Box::SetGeometry / Light::SetGeometry / Triangle ctor / UpdateAABB of
+    the host layer against the dump of the reference's own objects: every float bit-identical."""
+    s = host.mcrt_host_scene_create(which, 1.5, 10.0, point)
+    try:
+        got = _flatten(pkg, host, s)
+    finally:
+        host.mcrt_host_scene_destroy(s)
+    want = scene_of(name)
+    _same_scene(got, want)
+
+
+def test_host_obj_loader_is_index_correct(pkg, host, scene_of, tmp_path):
+    """TriangleMesh::LoadMesh replacement: quads fan-triangulated by their indices (the reference's loader
+    ignores them).  The box-stack geometry written as an OBJ gives BASELINE config 2."""
+    want = scene_of("config2")
+    stack = want.triangles[48:]                      # the 36 triangles scenes.config2 appended
+    pos = np.array([0.0, -4.0, 1.5], np.float32)
+    lines = ["# box stack", "o stack"]
+    faces = []
+    for q in range(0, len(stack), 2):                # (a,b,c),(a,c,d) -> quad a b c d
+        a, b, c, d = stack["v0"][q], stack["v1"][q], stack["v2"][q], stack["v2"][q + 1]
+        base = len(lines) - 2 + 1
+        for v in (a, b, c, d):
+            v = v - pos
+            lines.append("v %.9g %.9g %.9g" % tuple(float(x) for x in v))
+        faces.append("f %d/1/1 %d/2/1 %d/3/1 %d/4/1" % (base, base + 1, base + 2, base + 3))
+    path = tmp_path / "stack.obj"
+    path.write_text("\n".join(lines + faces) + "\n")
+    s = host.mcrt_host_scene_create(0, 1.5, 10.0, 0)
+    try:
+        # the example scene puts the light last; an OBJ added afterwards becomes object 11
+        n = host.mcrt_host_scene_add_obj(s, str(path).encode(), 0.0, -4.0, 1.5, 0.5)
+        assert n == 36
+        got = _flatten(pkg, host, s)
+    finally:
+        host.mcrt_host_scene_destroy(s)
+    mesh = got.objects[11]
+    assert mesh["kind"] == pkg.abi.OBJECT_MESH and mesh["triangle_count"] == 36
+    tri = got.triangles[mesh["first_triangle"]:]
+    # vertices survive the text round trip to within an ulp of the offset subtraction; topology is exact
+    assert np.allclose(tri["v0"], stack["v0"], atol=1e-6) and np.allclose(tri["v1"], stack["v1"], atol=1e-6)
+    assert np.allclose(tri["v2"], stack["v2"], atol=1e-6) and np.allclose(tri["normal"], stack["normal"], atol=1e-5)
+    assert host.mcrt_host_scene_add_obj(host.mcrt_host_scene_create(0, 1.5, 10.0, 0), b"/nonexistent.obj", 0, 0, 0, 0.5) == -1
+
+
+def _same_scene(got, want):
+    assert got.triangles.tobytes() == want.triangles.tobytes()
+    assert len(got.objects) == len(want.objects)
+    for field in want.objects.dtype.names:            # field by field: struct padding bytes carry no meaning
+        if field == "material":
+            for sub in want.objects["material"].dtype.names:
+                assert got.objects["material"][sub].tobytes() == want.objects["material"][sub].tobytes(), sub
+        else:
+            assert got.objects[field].tobytes() == want.objects[field].tobytes(), field
+
+
+# ------------------------------------------------------------------ python scene helpers
+def test_scene_helpers_match_reference_ctor(pkg, scene_of):
+    """scenes.config2/3 build on the reference's Cornell dump; the fixtures hold what the reference's own
+    Triangle ctor / UpdateAABB made of the same vertices."""
+    from mcrt_amd import scenes
+
+    base = scene_of("cornell")
+    for name, fn in (("config2", scenes.config2), ("config3", scenes.config3)):
+        _same_scene(fn(base), scene_of(name))
+    _same_scene(scenes.config4(base, n=2000, seed=42), scene_of("config4_2k"))
+
+
+def test_pcg32_reference_values():
+    from mcrt_amd import scenes
+
+    # PCG32 demo stream (seed 42, sequence 54): first outputs published with the generator
+    assert [hex(int(x)) for x in scenes.pcg32_stream(6, 42, 54)] == ["0xa15c02b7", "0x7b47f409", "0xba1d3330", "0x83d2f293", "0xbfa4784b", "0xcbed606e"]
+
+
+# ------------------------------------------------------------------ flat octree (host build, CPU replay)
+@pytest.mark.parametrize("name", SCENES)
+def test_octree_equals_brute_force_on_cpu(pkg, oracle, po, scene_of, golden, name):
+    flat = scene_of(name)
+    g = golden(f"hits_{name}.npz")
+    sc = oracle.scene(flat)
+    for accel in (None, pkg.AccelParams(1, 12, 0.0), pkg.AccelParams(16, 2, 0.0), pkg.AccelParams(2, 6, 1e-6)):
+        info, box, words, refs = pkg.build_scene_image(flat, accel)
+        st = po.OctreeStats()
+        obj, elem, t = oracle.intersect_octree(sc, box, words, refs, g["origins"], g["dirs"], stats=st)
+        assert np.array_equal(obj, g["obj"]) and np.array_equal(elem, g["elem"]) and np.array_equal(t, g["t"])
+        assert st.nodes >= st.rays
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_octree_structure_invariants(pkg, scene_of, name):
+    flat = scene_of(name)
+    info, box, words, refs = pkg.build_scene_image(flat)
+    n = info.node_count
+    assert n >= 1 and info.prim_count == int(sum(1 if o["kind"] == 0 else o["triangle_count"] for o in flat.objects))
+    seen = np.zeros(info.prim_count, bool)
+    visited = np.zeros(n, bool)
+    stack = [0]
+    while stack:
+        i = stack.pop()
+        assert not visited[i]
+        visited[i] = True
+        assert (box[i, :3] <= box[i, 3:]).all()
+        cw, rf = int(words[i, 0]), int(words[i, 1])
+        if rf != 0xFFFFFFFF:
+            k = rf
+            while True:
+                e = int(refs[k]); seen[e & 0x7FFFFFFF] = True; k += 1
+                if e & 0x80000000:
+                    break
+        base, mask = cw & 0xFFFFFF, cw >> 24
+        for c in range(bin(mask).count("1")):
+            child = base + c
+            assert 0 < child < n
+            # a child's box lies inside its parent's (both are padded unions clipped to nested cells)
+            assert (box[child, :3] >= box[i, :3] - 1e-3).all() and (box[child, 3:] <= box[i, 3:] + 1e-3).all()
+            stack.append(child)
+    assert visited.all()
+    drawable = np.ones(info.prim_count, bool)
+    p = 0
+    for o in flat.objects:                              # spheres with radius < FLT_EPSILON never intersect: not in the tree
+        if o["kind"] == 0:
+            drawable[p] = o["radius"] >= np.finfo(np.float32).eps
+            p += 1
+        else:
+            p += int(o["triangle_count"])
+    assert (seen == drawable).all()
+
+
+def test_flatten_rejects_bad_scenes(pkg, scene_of):
+    flat = scene_of("cornell")
+    bad = pkg.FlatScene(flat.objects.copy(), flat.triangles.copy(), flat.background)
+    bad.objects["kind"][0] = 9
+    with pytest.raises(pkg.McrtError) as e:
+        pkg.build_scene_image(bad)
+    assert e.value.code == 1
+    bad = pkg.FlatScene(flat.objects.copy(), flat.triangles.copy(), flat.background)
+    bad.triangles["v1"][3] = np.nan
+    with pytest.raises(pkg.McrtError):
+        pkg.build_scene_image(bad)
+    many = pkg.FlatScene(np.repeat(flat.objects[3:4], 65), flat.triangles, flat.background)
+    with pytest.raises(pkg.McrtError) as e:
+        pkg.build_scene_image(many)
+    assert e.value.code == 5
+    empty = pkg.FlatScene(flat.objects[:0], flat.triangles[:0], flat.background)
+    with pytest.raises(pkg.McrtError):
+        pkg.build_scene_image(empty)
+
+
+# ------------------------------------------------------------------ fixed-order trig
+def _ulps(a, b):
+    ia, ib = a.view(np.int32).astype(np.int64), b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia); ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+    return np.abs(ia - ib)
+
+
+def test_portable_trig_within_one_ulp_of_libm(oracle):
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(0, 2 * np.pi, 400000), rng.uniform(-20, 20, 100000), [0.0, np.pi / 2, np.pi, 3 * np.pi / 2]]).astype(np.float32)
+    for name, fn in (("sin", np.sin), ("cos", np.cos)):
+        got = oracle.portable_math(name, x)
+        want = fn(x.astype(np.float64)).astype(np.float32)        # correctly rounded
+        u = _ulps(got, want)
+        assert u.max() <= 1 and (u == 0).mean() > 0.9999, (name, u.max(), (u == 0).mean())
+    xa = np.concatenate([rng.uniform(-1, 1, 400000), [-1.0, 1.0, 0.0, 0.5, -0.5]]).astype(np.float32)
+    u = _ulps(oracle.portable_math("acos", xa), np.arccos(xa.astype(np.float64)).astype(np.float32))
+    assert u.max() <= 1 and (u == 0).mean() > 0.9999
+    assert np.isnan(oracle.portable_math("acos", np.array([1.0000001, -1.0000001, np.nan], np.float32))).all()
+    xt = rng.uniform(0, np.pi, 200000).astype(np.float32)
+    got, want = oracle.portable_math("tan", xt), np.tan(xt.astype(np.float64)).astype(np.float32)
+    assert _ulps(got, want).max() <= 1
+
+
+def test_oracle_modes_agree(oracle, pkg, scene_of, golden):
+    """portable trig and visiting-order sums (the GPU's modes) against libm and recursion order
+    (the reference's): same paths on >99 % of samples, differences of rounding size."""
+    g = golden("samples_config3.npz")
+    cam = pkg.abi.camera_from_numpy(g["camera"])
+    sc = oracle.scene(scene_of("config3"))
+    a = g["radiance"]
+    fwd = oracle.trace_samples(sc, cam, g["pixels"], g["samples"], int(g["seed"]), int(g["depth"]), forward_sum=True)
+    assert np.allclose(fwd, a, rtol=1e-13, atol=1e-15)
+    pm = oracle.trace_samples(sc, cam, g["pixels"], g["samples"], int(g["seed"]), int(g["depth"]), portable_math=True)
+    rel = np.abs(pm - a).max(axis=1) / np.maximum(np.abs(a).max(axis=1), 1e-3)
+    assert (rel < 1e-9).mean() > 0.99
