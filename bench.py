@@ -34,6 +34,8 @@ WORKLOADS = {
     "config2_1024_256": ("config2", 1024, 1024, 256),       # BASELINE config 2: the bench default
     "config3_1024_1024": ("config3", 1024, 1024, 1024),     # BASELINE config 3
     "cornell_4k_64": ("cornell", 3840, 2160, 64),           # one progressive pass of BASELINE config 5
+    "config4_2048_256": ("config4", 2048, 2048, 256),       # BASELINE config 4: 1M-triangle mesh (octree, HBM/L2 bound)
+    "config4_1024_16": ("config4", 1024, 1024, 16),         # the same scene, short run
 }
 
 
@@ -80,7 +82,13 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     scene_name, width, height, spp = WORKLOADS[args.workload]
-    flat = pkg.FlatScene.load(os.path.join(ROOT, "tests", "golden", f"scene_{scene_name}.npz"))
+    if scene_name == "config4":
+        from mcrt_amd import scenes
+
+        note("building the 1,000,000-triangle mesh")
+        flat = scenes.config4(pkg.FlatScene.load(os.path.join(ROOT, "tests", "golden", "scene_cornell.npz")), n=1_000_000, seed=42)
+    else:
+        flat = pkg.FlatScene.load(os.path.join(ROOT, "tests", "golden", f"scene_{scene_name}.npz"))
     cam = pkg.host_camera(width, height, 90.0, (0.0, 0.0, 5.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
 
     be = pkg.Backend(local_rank)

@@ -558,13 +558,13 @@ MCRT_DEV Hit cast_scan(CstPtr sm, CstPtr big, const SceneView& v, V3 o, V3 d, Co
             if (__ballot(pass) == 0ull) continue;             // nobody in the wave needs this mesh
             const uint32_t count = head.s2;
             CstPtr pr = big + v.off_pair + (size_t)rec[OBJ_FIRST_PAIR] * PAIR_STRIDE;
-            for (uint32_t k = 0; k < count; k += 2, pr += PAIR_STRIDE) {
-                if (pass) {
-                    const U16 w0 = *(const __attribute__((address_space(4))) U16*)pr;
-                    const U4 w1 = *(const __attribute__((address_space(4))) U4*)(pr + 16);
-                    const F2 v0x = f2(w0.s0, w0.s1), v0y = f2(w0.s2, w0.s3), v0z = f2(w0.s4, w0.s5);
-                    const F2 e1x = f2(w0.s6, w0.s7), e1y = f2(w0.s8, w0.s9), e1z = f2(w0.sa, w0.sb);
-                    const F2 e2x = f2(w0.sc, w0.sd), e2y = f2(w0.se, w0.sf), e2z = f2(w1.x, w1.y);
+            if (pass) {
+                for (uint32_t k = 0; k < count; k += 2, pr += PAIR_STRIDE) {
+                    const U16 c0 = *(const __attribute__((address_space(4))) U16*)pr;
+                    const U4 c1 = *(const __attribute__((address_space(4))) U4*)(pr + 16);
+                    const F2 v0x = f2(c0.s0, c0.s1), v0y = f2(c0.s2, c0.s3), v0z = f2(c0.s4, c0.s5);
+                    const F2 e1x = f2(c0.s6, c0.s7), e1y = f2(c0.s8, c0.s9), e1z = f2(c0.sa, c0.sb);
+                    const F2 e2x = f2(c0.sc, c0.sd), e2y = f2(c0.se, c0.sf), e2z = f2(c1.x, c1.y);
                     // Triangle::Intersects, source/core/triangle.h:31-60, both triangles at once
                     const F2 hx = d.y * e2z - e2y * d.z, hy = d.z * e2x - e2z * d.x, hz = d.x * e2y - e2x * d.y;   // cross(d, edge2)
                     const F2 a = dot2(e1x, e1y, e1z, hx, hy, hz);
