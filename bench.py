@@ -46,6 +46,22 @@ def algorithmic_bytes_per_sample(cnt, spp):
     return (cnt["nodes"] * 32 + cnt["tris"] * 36 + cnt["spheres"] * 16 + cnt["gates"] * 24) / s + 24.0 / spp + 4.0 / spp
 
 
+def measured_traffic(workload):
+    """HBM bytes per k_render launch from the committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json);
+    PMC counters cannot be collected from inside this process, so the latest committed measurement of the
+    same workload is reported, or null."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            entry = json.load(open(path)).get(workload)
+        except (OSError, ValueError):
+            continue
+        if entry:
+            return entry["traffic_bytes"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,7 +190,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-            "traffic": None,
+            "traffic": measured_traffic(args.workload),
             "kernel": "k_render", "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_sample": round(bytes_per_sample, 2),
             "per_sample": {k: round(v / max(cnt["samples"], 1), 4) for k, v in cnt.items() if k != "samples"},
             "note": "scene image is LDS-resident: the kernel is VALU/latency bound, HBM fraction is honest but small",

@@ -34,7 +34,7 @@ using namespace mcrt;
 namespace {
 
 constexpr int kBlock = 256;                 // 4 wavefronts
-constexpr uint32_t kPendFields = 14;        // words per parked reflect branch: o(3) d(3) importance(6) depth(1) pad(1)
+constexpr uint32_t kPendFields = 16;        // words per parked reflect branch: o(3) d(3) depth(1) pad(1) importance(6) pad(2) = one 64-byte line
 constexpr uint32_t kMaxDepthLimit = 256;    // bound on max_depth (size of the parked-branch stack)
 constexpr uint32_t kLdsBudgetBytes = 96 * 1024;  // whole-scene LDS residency threshold
 
@@ -90,11 +90,33 @@ template <bool kBigLds> struct SceneMem<kBigLds, MCRT_ACCEL_SCAN> {
 // branch runs.  One column per launched lane; fields interleaved so a wave touches consecutive words.
 struct PendStack {
     uint32_t* base;
-    uint32_t lanes;    // total launched lanes
-    uint32_t lane;     // this lane's column
-    __device__ __forceinline__ uint32_t* at(uint32_t entry, uint32_t field) const
+    uint32_t entries;  // capacity per lane (= max_depth)
+    uint32_t lane;     // this lane's global index
+    // one 64-byte line per (lane, entry): a push or pop touches exactly one line
+    __device__ __forceinline__ U4* line(uint32_t entry) const
     {
-        return base + ((size_t)entry * kPendFields + field) * lanes + lane;
+        return reinterpret_cast<U4*>(base + ((size_t)lane * entries + entry) * kPendFields);
+    }
+    __device__ __forceinline__ void push(uint32_t entry, V3 o, V3 d, D3 imp, uint32_t depth) const
+    {
+        U4* p = line(entry);
+        const uint64_t ix = (uint64_t)__double_as_longlong(imp.x), iy = (uint64_t)__double_as_longlong(imp.y), iz = (uint64_t)__double_as_longlong(imp.z);
+        U4 a, b, c, e;
+        a.x = __float_as_uint(o.x); a.y = __float_as_uint(o.y); a.z = __float_as_uint(o.z); a.w = __float_as_uint(d.x);
+        b.x = __float_as_uint(d.y); b.y = __float_as_uint(d.z); b.z = depth; b.w = 0;
+        c.x = (uint32_t)ix; c.y = (uint32_t)(ix >> 32); c.z = (uint32_t)iy; c.w = (uint32_t)(iy >> 32);
+        e.x = (uint32_t)iz; e.y = (uint32_t)(iz >> 32); e.z = 0; e.w = 0;
+        p[0] = a; p[1] = b; p[2] = c; p[3] = e;
+    }
+    __device__ __forceinline__ void pop(uint32_t entry, V3& o, V3& d, D3& imp, uint32_t& depth) const
+    {
+        const U4* p = line(entry);
+        const U4 a = p[0], b = p[1], c = p[2], e = p[3];
+        o = mk(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+        d = mk(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
+        depth = b.z;
+        imp = dmk(__longlong_as_double((long long)((uint64_t)c.x | ((uint64_t)c.y << 32))), __longlong_as_double((long long)((uint64_t)c.z | ((uint64_t)c.w << 32))),
+                  __longlong_as_double((long long)((uint64_t)e.x | ((uint64_t)e.y << 32))));
     }
 };
 
@@ -221,13 +243,7 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
                                 // the two operands of the `+` at scene.cpp:212-213; pinned by fixture F5)
                                 const V3 po = p + errorMargin, pd = reflect(I, n);
                                 const D3 pimp = imp * (double)R;
-                                *pend.at(npend, 0) = __float_as_uint(po.x); *pend.at(npend, 1) = __float_as_uint(po.y); *pend.at(npend, 2) = __float_as_uint(po.z);
-                                *pend.at(npend, 3) = __float_as_uint(pd.x); *pend.at(npend, 4) = __float_as_uint(pd.y); *pend.at(npend, 5) = __float_as_uint(pd.z);
-                                const uint64_t ix = (uint64_t)__double_as_longlong(pimp.x), iy = (uint64_t)__double_as_longlong(pimp.y), iz = (uint64_t)__double_as_longlong(pimp.z);
-                                *pend.at(npend, 6) = (uint32_t)ix; *pend.at(npend, 7) = (uint32_t)(ix >> 32);
-                                *pend.at(npend, 8) = (uint32_t)iy; *pend.at(npend, 9) = (uint32_t)(iy >> 32);
-                                *pend.at(npend, 10) = (uint32_t)iz; *pend.at(npend, 11) = (uint32_t)(iz >> 32);
-                                *pend.at(npend, 12) = depth - 1;
+                                pend.push(npend, po, pd, pimp, depth - 1);
                                 npend += 1;
                                 if (kCount) rc.splits++;
                                 imp = imp * (double)(1.0 - R);
@@ -285,13 +301,7 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
         if (branch_done) {
             if (npend > 0) {
                 npend -= 1;
-                ro = mk(__uint_as_float(*pend.at(npend, 0)), __uint_as_float(*pend.at(npend, 1)), __uint_as_float(*pend.at(npend, 2)));
-                rd = mk(__uint_as_float(*pend.at(npend, 3)), __uint_as_float(*pend.at(npend, 4)), __uint_as_float(*pend.at(npend, 5)));
-                const uint64_t ix = (uint64_t)*pend.at(npend, 6) | ((uint64_t)*pend.at(npend, 7) << 32);
-                const uint64_t iy = (uint64_t)*pend.at(npend, 8) | ((uint64_t)*pend.at(npend, 9) << 32);
-                const uint64_t iz = (uint64_t)*pend.at(npend, 10) | ((uint64_t)*pend.at(npend, 11) << 32);
-                imp = dmk(__longlong_as_double((long long)ix), __longlong_as_double((long long)iy), __longlong_as_double((long long)iz));
-                depth = *pend.at(npend, 12);
+                pend.pop(npend, ro, rd, imp, depth);
                 state = ST_TRACE;
             } else {
                 // PixelBuffer::Accumulate, source/core/pixelbuffer.cpp:39-46 (non-finite samples dropped)
@@ -341,7 +351,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_render(const RenderArgs a)
 
     PendStack pend;
     pend.base = a.pend;
-    pend.lanes = gridDim.x * blockDim.x;
+    pend.entries = a.max_depth ? a.max_depth : 1u;
     pend.lane = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     Counters cn = { 0, 0, 0, 0, 0 };
@@ -399,11 +409,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_list(const ListArgs a)
     Mem::open(a.view, smem, sm, big);
     PendStack pend;
     pend.base = a.pend;
-    pend.lanes = gridDim.x * blockDim.x;
+    pend.entries = a.max_depth ? a.max_depth : 1u;
     pend.lane = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t all_lanes = (uint64_t)gridDim.x * blockDim.x;
     Counters cn = { 0, 0, 0, 0, 0 };
     RenderCounters rc = { 0, 0, 0 };
-    for (uint64_t i = pend.lane; i < a.n; i += pend.lanes) {
+    for (uint64_t i = pend.lane; i < a.n; i += all_lanes) {
         D3 sum; uint32_t dropped;
         if (a.ray_o) {
             ExplicitStart ex;
