@@ -229,9 +229,8 @@ MCRT_DEV float pm_acosf(float xf)
 
 // ------------------------------------------------------------- primitives
 // Triangle::Intersects, source/core/triangle.h:25-62 (edges precomputed at upload).
-template <class P> MCRT_DEV bool tri_hit(P big, uint32_t rec, V3 o, V3 d, float& t)
+MCRT_DEV bool tri_hit_rec(const TriRec& tr, V3 o, V3 d, float& t)
 {
-    const TriRec tr = load_tri(big, rec);
     const V3 v0 = tr.v0, edge1 = tr.e1, edge2 = tr.e2;
     V3 h = cross(d, edge2);
     float a = dot(edge1, h);
@@ -245,6 +244,10 @@ template <class P> MCRT_DEV bool tri_hit(P big, uint32_t rec, V3 o, V3 d, float&
     if (v < 0.0f || u + v > 1.0f) return false;
     t = f * dot(edge2, q);
     return t > kFltEpsilon;
+}
+template <class P> MCRT_DEV bool tri_hit(P big, uint32_t rec, V3 o, V3 d, float& t)
+{
+    return tri_hit_rec(load_tri(big, rec), o, d, t);
 }
 
 // SphereObject::Intersects, source/objects/sphere.h:16-52
@@ -357,31 +360,39 @@ MCRT_DEV Hit cast_octree(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters
     const float ix = __frcp_rn(d.x), iy = __frcp_rn(d.y), iz = __frcp_rn(d.z);
     // visit octants front to back: flip the octant index on axes where the ray runs backwards
     const uint32_t flip = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
-    const uint32_t nn = v.nnode;
+    const PB nodes = big + v.off_node;
+    const PB leaves = big + v.off_leaf;
 
-    uint32_t stack_node[TRAVERSAL_STACK];
+    // A stack entry is everything a visit needs (entry distance, child word, leaf-list index), copied out
+    // of the child's record when the parent tested its box: a pop never re-reads the node.
     float stack_t[TRAVERSAL_STACK];
+    uint32_t stack_cw[TRAVERSAL_STACK], stack_leaf[TRAVERSAL_STACK];
     int sp = 0;
-    stack_node[sp] = 0; stack_t[sp] = 0.0f; ++sp;
+    {
+        const U4 root = ld4(nodes, 4);
+        stack_t[0] = 0.0f; stack_cw[0] = root.z; stack_leaf[0] = root.w; sp = 1;
+    }
 
     while (sp > 0) {
         --sp;
-        const uint32_t node = stack_node[sp];
         if (stack_t[sp] > best.t) continue;
+        const uint32_t cw = stack_cw[sp];
+        const uint32_t leaf = stack_leaf[sp];
         if (kCount) cn.nodes++;
 
-        uint32_t ref = big[v.off_node + NODE_REFS * nn + node];
-        if (ref != NO_REFS) {
-            uint32_t e;
-            do {
-                e = big[v.off_refs + ref++];
-                const uint32_t prim = e & ~REF_LAST;
-                const uint32_t obj = big[v.off_prim_obj + prim];
+        if (leaf != NO_REFS) {
+            uint32_t r = leaf * LEAF_STRIDE;
+            U4 a = ld4(leaves, r), b = ld4(leaves, r + 4), c = ld4(leaves, r + 8);
+            for (;;) {
+                r += LEAF_STRIDE;
+                // the next record of the stream is requested before this one is tested (the array ends in a pad record)
+                const U4 na = ld4(leaves, r), nb = ld4(leaves, r + 4), nc = ld4(leaves, r + 8);
+                const uint32_t prim = c.y & ~REF_LAST;
+                const uint32_t obj = c.z & ~LEAF_SPHERE;
                 const uint32_t orec = v.off_obj + obj * OBJ_STRIDE;
-                const uint32_t first_prim = sm[orec + OBJ_FIRST_PRIM];
                 float t;
                 bool h;
-                if (sm[orec + OBJ_KIND] == MCRT_OBJECT_SPHERE) {
+                if (c.z & LEAF_SPHERE) {
                     if (kCount) cn.spheres++;
                     h = sphere_hit(sm, orec, o, d, t);
                 } else {
@@ -395,38 +406,44 @@ MCRT_DEV Hit cast_octree(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters
                     h = false;
                     if (gate_pass & bit) {
                         if (kCount) cn.tris++;
-                        h = tri_hit(big, v.off_tri + (sm[orec + OBJ_FIRST_TRI] + (prim - first_prim)) * TRI_STRIDE, o, d, t);
+                        TriRec tr;
+                        tr.v0 = mk(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+                        tr.e1 = mk(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
+                        tr.e2 = mk(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x));
+                        h = tri_hit_rec(tr, o, d, t);
                     }
                 }
                 if (h && nearer(t, prim, best)) {
-                    best.prim = prim; best.obj = obj; best.elem = prim - first_prim; best.t = t;
+                    best.prim = prim; best.obj = obj; best.elem = prim - sm[orec + OBJ_FIRST_PRIM]; best.t = t;
                 }
-            } while (!(e & REF_LAST));
+                if (c.y & REF_LAST) break;
+                a = na; b = nb; c = nc;
+            }
         }
 
-        const uint32_t cw = big[v.off_node + NODE_CHILD * nn + node];
         const uint32_t mask = cw >> 24;
         if (mask) {
             const uint32_t base = cw & 0x00FFFFFFu;
-            // push far octants first so the nearest is popped first
-#pragma unroll 1
+            // All eight octant slots are fetched unconditionally (an absent octant re-reads the first child: same
+            // cache line) so the sixteen 16-byte loads are in flight together; far octants are pushed first so
+            // the nearest is popped first.
+#pragma unroll
             for (int k = 7; k >= 0; --k) {
                 const uint32_t oct = (uint32_t)k ^ flip;
-                if (!(mask & (1u << oct))) continue;
-                const uint32_t child = base + __popc(mask & ((1u << oct) - 1u));
+                const bool exists = (mask >> oct) & 1u;
+                const uint32_t child = exists ? base + __popc(mask & ((1u << oct) - 1u)) : base;
+                const U4 lo = ld4(nodes, child * NODE_STRIDE), hi = ld4(nodes, child * NODE_STRIDE + 4);
                 float t0 = 0.0f, t1 = best.t;
-                {
-                    float a = (ldf(big, v.off_node + NODE_MIN_X * nn + child) - o.x) * ix;
-                    float b = (ldf(big, v.off_node + NODE_MAX_X * nn + child) - o.x) * ix;
-                    t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
-                    a = (ldf(big, v.off_node + NODE_MIN_Y * nn + child) - o.y) * iy;
-                    b = (ldf(big, v.off_node + NODE_MAX_Y * nn + child) - o.y) * iy;
-                    t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
-                    a = (ldf(big, v.off_node + NODE_MIN_Z * nn + child) - o.z) * iz;
-                    b = (ldf(big, v.off_node + NODE_MAX_Z * nn + child) - o.z) * iz;
-                    t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
-                }
-                if (t0 <= t1) { stack_node[sp] = child; stack_t[sp] = t0; ++sp; }
+                float p = (__uint_as_float(lo.x) - o.x) * ix;
+                float q = (__uint_as_float(lo.w) - o.x) * ix;
+                t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
+                p = (__uint_as_float(lo.y) - o.y) * iy;
+                q = (__uint_as_float(hi.x) - o.y) * iy;
+                t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
+                p = (__uint_as_float(lo.z) - o.z) * iz;
+                q = (__uint_as_float(hi.y) - o.z) * iz;
+                t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
+                if (exists && t0 <= t1) { stack_t[sp] = t0; stack_cw[sp] = hi.z; stack_leaf[sp] = hi.w; ++sp; }
             }
         }
     }

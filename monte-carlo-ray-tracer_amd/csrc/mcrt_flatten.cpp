@@ -355,10 +355,8 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
 
     // ---- BIG image -------------------------------------------------------------------
     uint64_t off = 0;
-    v.off_node = uint32_t(off);      off += uint64_t(nnode) * NODE_ARRAYS;
-    v.off_refs = uint32_t(off);      off += out.refs.size();
-    v.off_prim_obj = uint32_t(off);  off += nprim;
-    off = (off + 3u) & ~uint64_t(3); // triangle records 16-byte aligned
+    v.off_node = uint32_t(off);      off += uint64_t(nnode) * NODE_STRIDE;
+    v.off_leaf = uint32_t(off);      off += (uint64_t(out.refs.size()) + 1u) * LEAF_STRIDE;   // +1: the traversal prefetches one record ahead
     v.off_tri = uint32_t(off);       off += uint64_t(sc->triangle_count) * TRI_STRIDE;
     // triangle-pair records for the scan path: only built for scenes it can be chosen for
     std::vector<uint32_t> first_pair(nobj, 0);
@@ -375,12 +373,11 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
     v.big_words = uint32_t(off);
     out.big_img.assign(v.big_words, 0u);
     for (uint32_t f = 0; f < nnode; ++f) {
-        for (uint32_t k = 0; k < 6; ++k) out.big_img[v.off_node + size_t(k) * nnode + f] = fbits(out.node_box[size_t(f) * 6 + k]);
-        out.big_img[v.off_node + size_t(NODE_CHILD) * nnode + f] = out.node_words[size_t(f) * 2];
-        out.big_img[v.off_node + size_t(NODE_REFS) * nnode + f] = out.node_words[size_t(f) * 2 + 1];
+        uint32_t* w = out.big_img.data() + v.off_node + size_t(f) * NODE_STRIDE;
+        for (uint32_t k = 0; k < 6; ++k) w[NODE_BOX + k] = fbits(out.node_box[size_t(f) * 6 + k]);
+        w[NODE_CHILD] = out.node_words[size_t(f) * 2];
+        w[NODE_LEAF] = out.node_words[size_t(f) * 2 + 1];
     }
-    std::copy(out.refs.begin(), out.refs.end(), out.big_img.begin() + v.off_refs);
-    std::copy(prim_obj.begin(), prim_obj.end(), out.big_img.begin() + v.off_prim_obj);
     for (uint32_t t = 0; t < sc->triangle_count; ++t) {
         const mcrt_triangle& tr = sc->triangles[t];
         uint32_t* w = out.big_img.data() + v.off_tri + size_t(t) * TRI_STRIDE;
@@ -392,6 +389,19 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
             w[TRI_E1 + a] = fbits(e1);
             w[TRI_E2 + a] = fbits(e2);
             w[TRI_N + a] = fbits(tr.normal[a]);
+        }
+    }
+    for (size_t r = 0; r < out.refs.size(); ++r) {
+        const uint32_t prim = out.refs[r] & ~REF_LAST;
+        const uint32_t obj = prim_obj[prim];
+        const mcrt_object& o = sc->objects[obj];
+        uint32_t* w = out.big_img.data() + v.off_leaf + r * LEAF_STRIDE;
+        w[LEAF_PRIM] = out.refs[r];
+        if (o.kind == MCRT_OBJECT_SPHERE) w[LEAF_OBJ] = obj | LEAF_SPHERE;
+        else {
+            w[LEAF_OBJ] = obj;
+            const uint32_t* tr = out.big_img.data() + v.off_tri + size_t(o.first_triangle + (prim - first_prim[obj])) * TRI_STRIDE;
+            for (uint32_t k = 0; k < 9; ++k) w[k] = tr[k];   // v0, e1, e2 are words 0..8 of both records
         }
     }
     if (want_pairs)

@@ -4,8 +4,9 @@
 //   SMALL: per-object records (geometry header, mesh gate box, light vectors,
 //          material), the light list and the background colour.  A few KB at
 //          most; every kernel stages it in LDS.
-//   BIG:   the flat octree (SoA node arrays + per-node primitive reference
-//          lists), the primitive->object table and the triangle records.
+//   BIG:   the flat octree (32-byte node records + per-node lists of 48-byte
+//          leaf records that carry the triangle they refer to), the triangle
+//          records and the triangle-pair records of the scan path.
 //          Staged in LDS when SMALL+BIG fit the LDS budget (all Cornell-box
 //          configurations), read from HBM/L2 otherwise (the 1M-triangle mesh).
 //
@@ -52,14 +53,27 @@ enum : uint32_t { TRI_V0 = 0, TRI_E1 = 3, TRI_E2 = 6, TRI_N = 9, TRI_STRIDE = 12
 // copy of itself (a repeated test can never win the strict `<`).
 enum : uint32_t { PAIR_V0 = 0, PAIR_E1 = 6, PAIR_E2 = 12, PAIR_STRIDE = 20 };
 
-// ---- octree node arrays (BIG image), SoA: array k lives at off_node + k*node_count
+// ---- octree node record (BIG image), NODE_STRIDE words each, 32-byte aligned: one record is two
+// 16-byte loads and the (up to 8) children of a node are contiguous, so a node visit touches
+// 256 contiguous bytes instead of one cache line per box coordinate.
 enum : uint32_t {
-    NODE_MIN_X = 0, NODE_MIN_Y = 1, NODE_MIN_Z = 2, NODE_MAX_X = 3, NODE_MAX_Y = 4, NODE_MAX_Z = 5,
+    NODE_BOX = 0,        // min.xyz, max.xyz (tight, padded)
     NODE_CHILD = 6,      // bits 0..23: index of the first child (children are contiguous,
                          // only non-empty octants are stored), bits 24..31: octant mask
-    NODE_REFS = 7,       // index of this node's first primitive reference, NO_REFS if none
-    NODE_ARRAYS = 8
+    NODE_LEAF = 7,       // index of this node's first leaf record, NO_REFS if none
+    NODE_STRIDE = 8
 };
+// ---- leaf record (BIG image), LEAF_STRIDE words each, 16-byte aligned.  One per (node, primitive)
+// reference, a node's records contiguous: the triangle's v0/edge1/edge2 are INLINED, so walking a
+// node's list is one sequential stream of 48-byte records (no ref -> object -> triangle pointer
+// chase).  A primitive referenced from several nodes is stored once per reference: HBM is plentiful.
+enum : uint32_t {
+    LEAF_V0 = 0, LEAF_E1 = 3, LEAF_E2 = 6,
+    LEAF_PRIM = 9,       // primitive id, REF_LAST set on the last record of the node's list
+    LEAF_OBJ = 10,       // object index, LEAF_SPHERE set for a sphere (geometry read from the object record)
+    LEAF_STRIDE = 12
+};
+constexpr uint32_t LEAF_SPHERE = 0x80000000u;
 constexpr uint32_t NO_REFS = 0xFFFFFFFFu;
 constexpr uint32_t REF_LAST = 0x80000000u;   // set on the last reference of a node's list
 constexpr uint32_t MISS = 0xFFFFFFFFu;
@@ -74,7 +88,7 @@ struct SceneView {
     uint32_t small_words, big_words;
     uint32_t nobj, nlights, ntri, nprim, nnode;
     uint32_t off_obj, off_lights, off_bg;            // into SMALL
-    uint32_t off_node, off_refs, off_prim_obj, off_tri, off_pair;  // into BIG
+    uint32_t off_node, off_leaf, off_tri, off_pair;  // into BIG (all multiples of 4 words)
     uint32_t has_pairs;          // triangle-pair records present (scan path usable)
 };
 
