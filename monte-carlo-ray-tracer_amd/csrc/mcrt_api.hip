@@ -158,8 +158,16 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
     D3 direct = dmk(0, 0, 0);
     uint32_t horec = 0, light_i = 0;
 
+    // Octree path: the nearest-hit query is resumable (OctreeWalk): lanes whose ray is finished are shaded
+    // and given their next ray while the others stay in mid-traversal.
+    constexpr bool kWalk = (kAccel == MCRT_ACCEL_OCTREE);
+    OctreeWalk<PS, PB, kCount> walk;
+    WalkStack walk_stack;
+    bool walking = false;
+    if (kWalk) walk.idle();
+
     while (state != ST_DONE) {
-        if (state == ST_NEW) {
+        if (state == ST_NEW && !walking) {
             // one iteration of the spp loop, source/main.cpp:122-139
             imp = dmk(1.0, 1.0, 1.0);
             if (ex) {
@@ -182,7 +190,16 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
             if (kCount) rc.samples++;
         }
 
-        const Hit hit = cast<kAccel, PS, PB, kCount>(sm, big, v, ro, rd, cn);
+        Hit hit;
+        if constexpr (kWalk) {
+            if (!walking) { walk.begin(big, v, walk_stack, cn); walking = true; }
+            walk.run(sm, big, v, walk_stack, ro, rd, cn, true);
+            if (!walk.done()) continue;                    // still in mid-traversal: nothing to shade yet
+            walking = false;
+            hit = walk.best;
+        } else {
+            hit = cast<kAccel, PS, PB, kCount>(sm, big, v, ro, rd, cn);
+        }
 
         bool branch_done = false;      // this TraceRay chain returned; continue with a parked branch or finish the sample
         bool after_lights = false;

@@ -349,35 +349,46 @@ MCRT_DEV Hit cast_brute(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters&
 // The mesh gate (source/objects/mesh.cpp:11-16) is a pure function of (ray,
 // mesh); it is evaluated the first time the ray meets a triangle of that mesh
 // and cached in two 64-bit masks.
-template <class PS, class PB, bool kCount>
-MCRT_DEV Hit cast_octree(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters& cn)
-{
-    Hit best; best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax;
-    if (kCount) cn.rays++;
-    uint64_t gate_known = 0, gate_pass = 0;
+//
+// The walk is RESUMABLE: run() returns to the caller as soon as enough lanes of the wavefront have
+// finished their ray, the caller shades those lanes, gives them their next ray and calls run()
+// again; lanes in mid-traversal simply carry on.  Ray lengths in a big scene are close to
+// exponentially distributed, so a wavefront that waits for its slowest lane on every query runs at
+// a fraction of its width; refilling keeps it above the exit threshold.  One iteration of run() is
+// one node visit: the node's leaf records (streamed, next record requested before the current one
+// is tested), then its eight child slots fetched together (sixteen 16-byte loads in flight).
+// A stack entry is everything a visit needs (entry distance, child word, leaf-list index), copied out
+// of the child's record when the parent tested its box: a pop never re-reads the node.
+struct WalkStack {
+    float t[TRAVERSAL_STACK];
+    uint32_t cw[TRAVERSAL_STACK], leaf[TRAVERSAL_STACK];
+};
 
-    // Node culling is conservative (boxes are padded at build time), so fast reciprocals are fine here.
-    const float ix = __frcp_rn(d.x), iy = __frcp_rn(d.y), iz = __frcp_rn(d.z);
-    // visit octants front to back: flip the octant index on axes where the ray runs backwards
-    const uint32_t flip = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
-    const PB nodes = big + v.off_node;
-    const PB leaves = big + v.off_leaf;
+template <class PS, class PB, bool kCount> struct OctreeWalk {
+    Hit best;
+    uint64_t gate_known, gate_pass;
+    int sp;               // entries on the stack; 0: the ray is finished, `best` is its answer
 
-    // A stack entry is everything a visit needs (entry distance, child word, leaf-list index), copied out
-    // of the child's record when the parent tested its box: a pop never re-reads the node.
-    float stack_t[TRAVERSAL_STACK];
-    uint32_t stack_cw[TRAVERSAL_STACK], stack_leaf[TRAVERSAL_STACK];
-    int sp = 0;
+    MCRT_DEV bool done() const { return sp == 0; }
+    MCRT_DEV void idle() { sp = 0; gate_known = gate_pass = 0; best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax; }
+
+    MCRT_DEV void begin(PB big, const SceneView& v, WalkStack& st, Counters& cn)
     {
-        const U4 root = ld4(nodes, 4);
-        stack_t[0] = 0.0f; stack_cw[0] = root.z; stack_leaf[0] = root.w; sp = 1;
+        best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax;
+        if (kCount) cn.rays++;
+        gate_known = 0; gate_pass = 0;
+        const U4 root = ld4(big + v.off_node, 4);
+        st.t[0] = 0.0f; st.cw[0] = root.z; st.leaf[0] = root.w; sp = 1;
     }
 
-    while (sp > 0) {
+    // One node visit.
+    MCRT_DEV void visit(PS sm, PB nodes, PB leaves, const SceneView& v, WalkStack& st, V3 o, V3 d, float ix, float iy, float iz, uint32_t flip,
+                        Counters& cn)
+    {
         --sp;
-        if (stack_t[sp] > best.t) continue;
-        const uint32_t cw = stack_cw[sp];
-        const uint32_t leaf = stack_leaf[sp];
+        if (st.t[sp] > best.t) return;            // entered behind the best hit so far
+        const uint32_t cw = st.cw[sp];
+        const uint32_t leaf = st.leaf[sp];
         if (kCount) cn.nodes++;
 
         if (leaf != NO_REFS) {
@@ -443,11 +454,39 @@ MCRT_DEV Hit cast_octree(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters
                 p = (__uint_as_float(lo.z) - o.z) * iz;
                 q = (__uint_as_float(hi.y) - o.z) * iz;
                 t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
-                if (exists && t0 <= t1) { stack_t[sp] = t0; stack_cw[sp] = hi.z; stack_leaf[sp] = hi.w; ++sp; }
+                if (exists && t0 <= t1) { st.t[sp] = t0; st.cw[sp] = hi.z; st.leaf[sp] = hi.w; ++sp; }
             }
         }
     }
-    return best;
+
+    // Advance every unfinished lane.  refill == false: until all lanes of the wavefront are finished.
+    // refill == true: return once fewer than ~70 % of the lanes that came in unfinished are still walking.
+    MCRT_DEV void run(PS sm, PB big, const SceneView& v, WalkStack& st, V3 o, V3 d, Counters& cn, bool refill)
+    {
+        // Node culling is conservative (boxes are padded at build time), so fast reciprocals are fine here.
+        const float ix = __frcp_rn(d.x), iy = __frcp_rn(d.y), iz = __frcp_rn(d.z);
+        // visit octants front to back: flip the octant index on axes where the ray runs backwards
+        const uint32_t flip = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+        const PB nodes = big + v.off_node;
+        const PB leaves = big + v.off_leaf;
+        const uint32_t entered = (uint32_t)__popcll(__ballot(sp > 0));
+        const uint32_t keep = refill ? (entered * 45u + 63u) / 64u : 1u;    // leave when fewer than this many are walking
+        for (;;) {
+            const uint32_t walking = (uint32_t)__popcll(__ballot(sp > 0));
+            if (walking == 0 || walking < keep) break;
+            if (sp > 0) visit(sm, nodes, leaves, v, st, o, d, ix, iy, iz, flip, cn);
+        }
+    }
+};
+
+template <class PS, class PB, bool kCount>
+MCRT_DEV Hit cast_octree(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters& cn)
+{
+    OctreeWalk<PS, PB, kCount> w;
+    WalkStack st;
+    w.begin(big, v, st, cn);
+    w.run(sm, big, v, st, o, d, cn, false);
+    return w.best;
 }
 
 // ---------------------------------------------------------------- wave-uniform scan
