@@ -27,6 +27,7 @@
 
 #include "mcrt.h"
 #include "mcrt_device.h"
+#include <cstdlib>
 #include "mcrt_flatten.h"
 
 using namespace mcrt;
@@ -140,7 +141,7 @@ template <class PS, class PB, int kAccel, bool kCount>
 __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, const CameraDev& cam, uint32_t pixel, uint32_t s_begin,
                                            uint32_t s_count, uint64_t seed, uint32_t max_depth, const PendStack& pend,
                                            bool keep_nonfinite, D3& sum, uint32_t& dropped, Counters& cn, RenderCounters& rc,
-                                           const ExplicitStart* ex = nullptr)
+                                           const ExplicitStart* ex = nullptr, uint32_t refill = 0u)
 {
     sum = dmk(0.0, 0.0, 0.0);
     dropped = 0;
@@ -193,7 +194,7 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
         Hit hit;
         if constexpr (kWalk) {
             if (!walking) { walk.begin(big, v, walk_stack, cn); walking = true; }
-            walk.run(sm, big, v, walk_stack, ro, rd, cn, true);
+            walk.run(sm, big, v, walk_stack, ro, rd, cn, refill);
             if (!walk.done()) continue;                    // still in mid-traversal: nothing to shade yet
             walking = false;
             hit = walk.best;
@@ -342,6 +343,7 @@ struct RenderArgs {
     uint32_t* pend;
     uint32_t s_begin, s_count, max_depth;
     uint32_t tiles_x, tiles;
+    uint32_t refill;            // octree walk: leave the walk loop below refill/64 of the lanes that entered (0: never)
     uint64_t seed;
 };
 
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_render(const RenderArgs a)
         const uint32_t pixel = inside ? y * a.cam.width + x : 0u;
         D3 sum; uint32_t dropped;
         trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, pixel, a.s_begin, inside ? a.s_count : 0u,
-                                                                          a.seed, a.max_depth, pend, false, sum, dropped, cn, rc);
+                                                                          a.seed, a.max_depth, pend, false, sum, dropped, cn, rc, nullptr, a.refill);
         if (inside) {
             double* px = a.accum + (size_t)pixel * 3;
             px[0] += sum.x; px[1] += sum.y; px[2] += sum.z;
@@ -572,6 +574,7 @@ struct mcrt_ctx {
     uint32_t* d_pend = nullptr;
     size_t pend_words = 0;
     uint32_t grid_blocks = 0;
+    int refill_override = -1;                   // MCRT_REFILL (tuning knob): see RenderArgs::refill
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -730,6 +733,7 @@ int mcrt_create(int device_id, mcrt_ctx** out_ctx)
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* e = getenv("MCRT_REFILL")) { int r = atoi(e); if (r >= 0 && r <= 64) c->refill_override = r; }
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     c->stream = c->own_stream;
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
@@ -1027,6 +1031,9 @@ int mcrt_render(mcrt_ctx* c, uint32_t sample_begin, uint32_t sample_count, uint3
     RenderArgs a;
     a.view = c->view; a.cam = c->cam; a.accum = c->d_accum; a.tile_counter = c->d_tile; a.counters = c->d_counters; a.pend = c->d_pend;
     a.s_begin = sample_begin; a.s_count = sample_count; a.max_depth = max_depth;
+    // measured (profiles/r01_refill_sweep.txt): refilling pays when the image is walked from HBM/L2 (long,
+    // exponentially distributed walks); with an LDS-resident image the extra shading passes cost more than they save
+    a.refill = c->refill_override >= 0 ? (uint32_t)c->refill_override : (c->big_in_lds ? 0u : 32u);
     a.tiles_x = (c->cam.width + 7u) / 8u;
     a.tiles = a.tiles_x * ((c->cam.height + 7u) / 8u);
     a.seed = seed;

@@ -459,9 +459,9 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
         }
     }
 
-    // Advance every unfinished lane.  refill == false: until all lanes of the wavefront are finished.
-    // refill == true: return once fewer than ~70 % of the lanes that came in unfinished are still walking.
-    MCRT_DEV void run(PS sm, PB big, const SceneView& v, WalkStack& st, V3 o, V3 d, Counters& cn, bool refill)
+    // Advance every unfinished lane.  refill == 0: until all lanes of the wavefront are finished; otherwise
+    // return once fewer than refill/64 of the lanes that came in unfinished are still walking.
+    MCRT_DEV void run(PS sm, PB big, const SceneView& v, WalkStack& st, V3 o, V3 d, Counters& cn, uint32_t refill)
     {
         // Node culling is conservative (boxes are padded at build time), so fast reciprocals are fine here.
         const float ix = __frcp_rn(d.x), iy = __frcp_rn(d.y), iz = __frcp_rn(d.z);
@@ -470,7 +470,7 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
         const PB nodes = big + v.off_node;
         const PB leaves = big + v.off_leaf;
         const uint32_t entered = (uint32_t)__popcll(__ballot(sp > 0));
-        const uint32_t keep = refill ? (entered * 45u + 63u) / 64u : 1u;    // leave when fewer than this many are walking
+        const uint32_t keep = (entered * refill + 63u) / 64u;    // leave when fewer than this many are walking
         for (;;) {
             const uint32_t walking = (uint32_t)__popcll(__ballot(sp > 0));
             if (walking == 0 || walking < keep) break;
@@ -485,7 +485,7 @@ MCRT_DEV Hit cast_octree(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters
     OctreeWalk<PS, PB, kCount> w;
     WalkStack st;
     w.begin(big, v, st, cn);
-    w.run(sm, big, v, st, o, d, cn, false);
+    w.run(sm, big, v, st, o, d, cn, 0u);
     return w.best;
 }
 
