@@ -236,6 +236,20 @@ int mcrt_accumulator(mcrt_ctx* ctx, double** out_d_accum);
 int mcrt_render(mcrt_ctx* ctx, uint32_t sample_begin, uint32_t sample_count,
                 uint32_t max_depth, uint64_t seed);
 
+/* Summation order of one mcrt_render pass.  The reference adds a pixel's
+ * samples one by one in sample order (PixelBuffer::Accumulate,
+ * source/core/pixelbuffer.cpp:39-46).  A pass does the same unless the image
+ * has too few pixels to fill the GPU: then each pixel's sample range is cut
+ * into L contiguous slices (slice l = samples [l*per, (l+1)*per), per =
+ * sample_count / L, the last slice takes the remainder) that run on different
+ * lanes; each slice is summed in sample order, and the pass adds
+ * ((slice0 + slice1) + slice2) + ... to the accumulator.  L is a pure function
+ * of (width, height, sample_count) - this one - so results never depend on
+ * scheduling or on the number of GPUs.  mcrt_set_lanes_per_pixel forces L
+ * (1 = exactly the reference's order; 0 = automatic, the default). */
+uint32_t mcrt_lanes_per_pixel(uint32_t width, uint32_t height, uint32_t sample_count);
+int mcrt_set_lanes_per_pixel(mcrt_ctx* ctx, uint32_t lanes);
+
 /* Milliseconds the last mcrt_render launch took on the device, from HIP
  * events recorded on the context's stream around the kernel (synchronises). */
 int mcrt_last_render_ms(mcrt_ctx* ctx, float* out_ms);

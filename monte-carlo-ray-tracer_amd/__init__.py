@@ -24,6 +24,7 @@ ABI_SYMBOLS = (
     "mcrt_camera_rays", "mcrt_intersect", "mcrt_intersect_device", "mcrt_trace_samples", "mcrt_trace_rays", "mcrt_render_unlit", "mcrt_rng_seed",
     "mcrt_clear", "mcrt_bind_accumulator", "mcrt_accumulator", "mcrt_render", "mcrt_last_render_ms", "mcrt_resolve",
     "mcrt_read_accumulator", "mcrt_synchronize", "mcrt_octree_info_get", "mcrt_octree_download", "mcrt_set_counting", "mcrt_counters",
+    "mcrt_lanes_per_pixel", "mcrt_set_lanes_per_pixel",
     "mcrt_camera_look_at", "mcrt_scene_image_create", "mcrt_scene_image_destroy", "mcrt_scene_image_info", "mcrt_scene_image_octree",
 )
 
@@ -36,10 +37,11 @@ class McrtError(RuntimeError):
         self.code = code
 
 
-def load_library(path=LIB_PATH):
-    """dlopen the HIP library (needs libamdhip64, not a GPU)."""
+def load_library(path=None):
+    """dlopen the HIP library (needs libamdhip64, not a GPU).  MCRT_LIB points at another build for A/B timing."""
     global _lib
     if _lib is None:
+        path = path or os.environ.get("MCRT_LIB") or LIB_PATH
         if not os.path.exists(path):
             raise FileNotFoundError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` or make -C {HERE}/csrc")
         lib = C.CDLL(path)
@@ -48,6 +50,12 @@ def load_library(path=LIB_PATH):
         lib.mcrt_rng_seed.restype = None
         _lib = lib
     return _lib
+
+
+def lanes_per_pixel(width, height, sample_count):
+    lib = load_library()
+    lib.mcrt_lanes_per_pixel.restype = C.c_uint32
+    return int(lib.mcrt_lanes_per_pixel(C.c_uint32(width), C.c_uint32(height), C.c_uint32(sample_count)))
 
 
 def rng_seed(seed, pixel, sample):
@@ -109,6 +117,7 @@ class Backend:
         if rc:
             raise McrtError(rc, (self.lib.mcrt_last_error(None) or b"").decode())
         self.width = self.height = 0
+        self._lanes = 0
 
     def close(self):
         if getattr(self, "ctx", None) and self.ctx.value:
@@ -214,6 +223,16 @@ class Backend:
 
     def render(self, sample_begin, sample_count, max_depth, seed):
         self._ck(self.lib.mcrt_render(self.ctx, C.c_uint32(sample_begin), C.c_uint32(sample_count), C.c_uint32(max_depth), C.c_uint64(seed)))
+
+    def lanes_per_pixel(self, sample_count):
+        """Sample slices per pixel the next render(…, sample_count, …) pass uses (the summation order, see include/mcrt.h)."""
+        if self._lanes:
+            return min(self._lanes, int(sample_count))
+        return lanes_per_pixel(self.width, self.height, sample_count)
+
+    def set_lanes_per_pixel(self, lanes):
+        self._ck(self.lib.mcrt_set_lanes_per_pixel(self.ctx, C.c_uint32(lanes)))
+        self._lanes = int(lanes)
 
     def last_render_ms(self):
         ms = C.c_float()

@@ -123,7 +123,7 @@ struct PendStack {
 
 struct RenderCounters { uint32_t samples, trace_calls, splits; };
 
-enum : uint32_t { ST_NEW = 0, ST_TRACE = 1, ST_SHADOW = 2, ST_DONE = 3 };
+enum : uint32_t { ST_NEW = 0, ST_TRACE = 1, ST_SHADOW = 2, ST_DONE = 3, ST_FETCH = 4 };
 
 // Explicit start of a TraceRay call (mcrt_trace_rays): ray, generator state and importance come from
 // the caller instead of the camera / counter seed; the advanced generator state is written back.
@@ -134,21 +134,24 @@ struct ExplicitStart {
     const double* importance;   // may be null: (1,1,1)
 };
 
-// One lane: samples [s_begin, s_begin + s_count) of `pixel`.  Returns the sum of the finite
-// samples in sample order (keep_nonfinite: return the raw value, used by the parity path with
-// s_count == 1) and the number dropped.
-template <class PS, class PB, int kAccel, bool kCount>
-__device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, const CameraDev& cam, uint32_t pixel, uint32_t s_begin,
-                                           uint32_t s_count, uint64_t seed, uint32_t max_depth, const PendStack& pend,
-                                           bool keep_nonfinite, D3& sum, uint32_t& dropped, Counters& cn, RenderCounters& rc,
-                                           const ExplicitStart* ex = nullptr, uint32_t refill = 0u)
+// One lane of a tracing kernel.  `work` hands out items - samples [s_begin, s_begin + s_count) of a
+// pixel - one at a time (Work::next) and takes back the sum of the item's finite samples in sample
+// order plus the number dropped (Work::done; keep_nonfinite: the raw value, used by the parity path
+// with s_count == 1).  Lanes fetch on their own: a lane that finishes early does not wait for its
+// wavefront.
+template <class PS, class PB, int kAccel, bool kCount, class Work>
+__device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, const CameraDev& cam, uint64_t seed, uint32_t max_depth,
+                                           const PendStack& pend, bool keep_nonfinite, Counters& cn, RenderCounters& rc, Work& work,
+                                           uint32_t refill)
 {
-    sum = dmk(0.0, 0.0, 0.0);
-    dropped = 0;
-    const uint32_t px = pixel % cam.width, py = pixel / cam.width;
+    D3 sum = dmk(0.0, 0.0, 0.0);
+    uint32_t dropped = 0;
+    uint32_t pixel = 0, s_begin = 0, s_count = 0, px = 0, py = 0;
+    ExplicitStart exs;
+    const ExplicitStart* ex = nullptr;
     const D3 background = ldd3(sm, v.off_bg);
 
-    uint32_t state = s_count ? ST_NEW : ST_DONE;
+    uint32_t state = ST_FETCH;
     uint32_t k = 0;
     Rng g; g.s0 = 0; g.s1 = 0;
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);       // ray of the current query
@@ -168,6 +171,13 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
     if (kWalk) walk.idle();
 
     while (state != ST_DONE) {
+        if (state == ST_FETCH) {
+            if (!work.next(pixel, s_begin, s_count)) { state = ST_DONE; continue; }
+            ex = work.explicit_start(exs) ? &exs : nullptr;
+            px = pixel % cam.width; py = pixel / cam.width;
+            k = 0; sum = dmk(0.0, 0.0, 0.0); dropped = 0;
+            state = ST_NEW;
+        }
         if (state == ST_NEW && !walking) {
             // one iteration of the spp loop, source/main.cpp:122-139
             imp = dmk(1.0, 1.0, 1.0);
@@ -328,7 +338,8 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
                 else dropped += 1;
                 if (ex) { ex->state[0] = g.s0; ex->state[1] = g.s1; }
                 k += 1;
-                state = (k < s_count) ? ST_NEW : ST_DONE;
+                if (k < s_count) state = ST_NEW;
+                else { work.done(pixel, sum, dropped); state = ST_FETCH; }
             }
         }
     }
@@ -338,11 +349,14 @@ struct RenderArgs {
     SceneView view;
     CameraDev cam;
     double* accum;
-    uint32_t* tile_counter;     // [0] next tile, [1] dropped samples
+    double* partial;            // [slices][pixels][3] when slices > 1
+    uint32_t* tile_counter;     // [0] next work item, [1] dropped samples
     unsigned long long* counters;   // 8 x u64 (kCount builds)
     uint32_t* pend;
     uint32_t s_begin, s_count, max_depth;
-    uint32_t tiles_x, tiles;
+    uint32_t tiles_x, tiles;    // 8x8 pixel tiles
+    uint32_t slices;            // sample slices per pixel (mcrt_lanes_per_pixel)
+    uint32_t items;             // tiles * 64 * slices
     uint32_t refill;            // octree walk: leave the walk loop below refill/64 of the lanes that entered (0: never)
     uint64_t seed;
 };
@@ -359,6 +373,71 @@ __device__ __forceinline__ void flush_counters(unsigned long long* out, const Co
     atomicAdd(out + 7, (unsigned long long)rc.splits);
 }
 
+// Work items of a render pass: item i = (slice, 8x8 tile, pixel in tile), handed out by one atomic counter in
+// tile order, so the lanes of a wavefront start on one tile and drift apart only as their paths differ in length.
+// Slice l of a pixel renders samples [l*per, (l+1)*per) (the last slice takes the remainder), per = s_count / slices.
+// slices == 1: the lane owns its pixel and adds its sum to the accumulator.  slices > 1 (small images, where
+// pixels alone cannot fill the GPU): the slice sums go to `partial` and k_combine adds them in slice order - the
+// summation order is fixed by (width, height, s_count) alone, never by scheduling.
+//
+// kRounds: the wavefront fetches in rounds - k_render takes 64 consecutive items (one tile of one slice) for the
+// whole wavefront, every lane works its item off, then the wavefront fetches again - which keeps its 64 lanes on
+// one tile (coherent rays: the wave-uniform scan culls whole meshes per wavefront; measured 9 % faster than
+// free-running lanes on the Cornell configurations).  Otherwise lanes fetch on their own whenever they run dry
+// (long incoherent walks through a big octree, where waiting for the slowest lane costs more than coherence gains).
+template <bool kRounds> struct RenderWork {
+    const RenderArgs& a;
+    uint32_t slice;
+    uint32_t dropped_total;
+    uint32_t item;        // kRounds: this lane's item of the current round
+    bool armed;
+    __device__ __forceinline__ bool decode(uint32_t i, uint32_t& pixel, uint32_t& s_begin, uint32_t& s_count)
+    {
+        const uint32_t t = i >> 6, within = i & 63u;
+        const uint32_t tile = t % a.tiles;
+        slice = t / a.tiles;
+        const uint32_t x = (tile % a.tiles_x) * 8u + (within & 7u), y = (tile / a.tiles_x) * 8u + (within >> 3);
+        if (x >= a.cam.width || y >= a.cam.height) return false;
+        pixel = y * a.cam.width + x;
+        const uint32_t per = a.s_count / a.slices;
+        s_begin = a.s_begin + slice * per;
+        s_count = (slice + 1u == a.slices) ? a.s_count - slice * per : per;
+        return true;
+    }
+    __device__ __forceinline__ bool next(uint32_t& pixel, uint32_t& s_begin, uint32_t& s_count)
+    {
+        if (kRounds) {
+            if (!armed) return false;
+            armed = false;
+            return decode(item, pixel, s_begin, s_count);
+        }
+        for (;;) {
+            // one atomic per wavefront for all lanes fetching together
+            const uint64_t fetching = __ballot(1);
+            const uint32_t me = threadIdx.x & 63u;
+            const uint32_t leader = (uint32_t)__ffsll((unsigned long long)fetching) - 1u;
+            uint32_t base = 0;
+            if (me == leader) base = atomicAdd(a.tile_counter, (uint32_t)__popcll(fetching));
+            base = (uint32_t)__shfl((int)base, (int)leader);
+            const uint32_t i = base + (uint32_t)__popcll(fetching & ((1ull << me) - 1ull));
+            if (i >= a.items) return false;
+            if (decode(i, pixel, s_begin, s_count)) return true;
+        }
+    }
+    __device__ __forceinline__ bool explicit_start(ExplicitStart&) const { return false; }
+    __device__ __forceinline__ void done(uint32_t pixel, const D3& sum, uint32_t dropped)
+    {
+        if (a.slices == 1u) {
+            double* px = a.accum + (size_t)pixel * 3;
+            px[0] += sum.x; px[1] += sum.y; px[2] += sum.z;
+        } else {
+            double* px = a.partial + ((size_t)slice * a.cam.width * a.cam.height + pixel) * 3;
+            px[0] = sum.x; px[1] = sum.y; px[2] = sum.z;
+        }
+        dropped_total += dropped;
+    }
+};
+
 template <bool kBigLds, int kAccel, bool kCount>
 __global__ __launch_bounds__(kBlock, 4) void k_render(const RenderArgs a)
 {
@@ -372,32 +451,36 @@ __global__ __launch_bounds__(kBlock, 4) void k_render(const RenderArgs a)
     pend.base = a.pend;
     pend.entries = a.max_depth ? a.max_depth : 1u;
     pend.lane = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63u;
     Counters cn = { 0, 0, 0, 0, 0 };
     RenderCounters rc = { 0, 0, 0 };
-    uint32_t dropped_total = 0;
-
-    for (;;) {
-        // every wavefront pulls its own 8x8 tile; exit when the counter runs past the last tile
-        uint32_t tile = 0;
-        if (lane == 0) tile = atomicAdd(a.tile_counter, 1u);
-        tile = (uint32_t)__shfl((int)tile, 0);
-        if (tile >= a.tiles) break;
-        const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-        const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
-        const bool inside = x < a.cam.width && y < a.cam.height;
-        const uint32_t pixel = inside ? y * a.cam.width + x : 0u;
-        D3 sum; uint32_t dropped;
-        trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, pixel, a.s_begin, inside ? a.s_count : 0u,
-                                                                          a.seed, a.max_depth, pend, false, sum, dropped, cn, rc, nullptr, a.refill);
-        if (inside) {
-            double* px = a.accum + (size_t)pixel * 3;
-            px[0] += sum.x; px[1] += sum.y; px[2] += sum.z;
+    constexpr bool kRounds = kBigLds || kAccel == MCRT_ACCEL_SCAN;
+    RenderWork<kRounds> work = { a, 0u, 0u, 0u, false };
+    if (kRounds) {
+        const uint32_t lane = threadIdx.x & 63u;
+        for (;;) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(a.tile_counter, 64u);
+            base = (uint32_t)__shfl((int)base, 0);
+            if (base >= a.items) break;                      // wave-uniform
+            work.item = base + lane; work.armed = true;
+            trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, false, cn, rc, work, a.refill);
         }
-        dropped_total += dropped;
+    } else {
+        trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, false, cn, rc, work, a.refill);
     }
-    if (dropped_total) atomicAdd(a.tile_counter + 1, dropped_total);
+    if (work.dropped_total) atomicAdd(a.tile_counter + 1, work.dropped_total);
     if (kCount) flush_counters(a.counters, cn, rc);
+}
+
+// accumulator += ((slice 0 + slice 1) + slice 2) + ... per pixel and channel: the order the test oracle uses
+__global__ __launch_bounds__(kBlock) void k_combine(double* __restrict__ accum, const double* __restrict__ partial, uint64_t values, uint32_t slices)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < values; i += stride) {
+        double tot = partial[i];
+        for (uint32_t l = 1; l < slices; ++l) tot += partial[(uint64_t)l * values + i];
+        accum[i] += tot;
+    }
 }
 
 struct ListArgs {
@@ -416,6 +499,33 @@ struct ListArgs {
     const float* ray_d;
     uint64_t* ray_state;
     const double* ray_importance;
+    uint32_t refill;
+};
+
+// Work items of mcrt_trace_samples / mcrt_trace_rays: entry i of the caller's arrays, grid-strided per lane.
+struct ListWork {
+    const ListArgs& a;
+    uint64_t i, stride, cur;
+    __device__ __forceinline__ bool next(uint32_t& pixel, uint32_t& s_begin, uint32_t& s_count)
+    {
+        if (i >= a.n) return false;
+        cur = i; i += stride;
+        pixel = a.ray_o ? 0u : a.pixels[cur];
+        s_begin = a.ray_o ? 0u : a.samples[cur];
+        s_count = 1u;
+        return true;
+    }
+    __device__ __forceinline__ bool explicit_start(ExplicitStart& e) const
+    {
+        if (!a.ray_o) return false;
+        e.o = a.ray_o + 3 * cur; e.d = a.ray_d + 3 * cur; e.state = a.ray_state + 2 * cur;
+        e.importance = a.ray_importance ? a.ray_importance + 3 * cur : nullptr;
+        return true;
+    }
+    __device__ __forceinline__ void done(uint32_t, const D3& sum, uint32_t)
+    {
+        a.out[3 * cur] = sum.x; a.out[3 * cur + 1] = sum.y; a.out[3 * cur + 2] = sum.z;
+    }
 };
 
 template <bool kBigLds, int kAccel, bool kCount>
@@ -430,22 +540,10 @@ __global__ __launch_bounds__(kBlock) void k_trace_list(const ListArgs a)
     pend.base = a.pend;
     pend.entries = a.max_depth ? a.max_depth : 1u;
     pend.lane = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t all_lanes = (uint64_t)gridDim.x * blockDim.x;
     Counters cn = { 0, 0, 0, 0, 0 };
     RenderCounters rc = { 0, 0, 0 };
-    for (uint64_t i = pend.lane; i < a.n; i += all_lanes) {
-        D3 sum; uint32_t dropped;
-        if (a.ray_o) {
-            ExplicitStart ex;
-            ex.o = a.ray_o + 3 * i; ex.d = a.ray_d + 3 * i; ex.state = a.ray_state + 2 * i;
-            ex.importance = a.ray_importance ? a.ray_importance + 3 * i : nullptr;
-            trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, 0u, 0u, 1u, a.seed, a.max_depth, pend, true,
-                                                                          sum, dropped, cn, rc, &ex);
-        } else
-        trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, a.pixels[i], a.samples[i], 1u, a.seed,
-                                                                          a.max_depth, pend, true, sum, dropped, cn, rc);
-        a.out[3 * i] = sum.x; a.out[3 * i + 1] = sum.y; a.out[3 * i + 2] = sum.z;
-    }
+    ListWork work = { a, pend.lane, (uint64_t)gridDim.x * blockDim.x, 0 };
+    trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, true, cn, rc, work, a.refill);
     if (kCount) flush_counters(a.counters, cn, rc);
 }
 
@@ -574,6 +672,9 @@ struct mcrt_ctx {
     uint32_t* d_pend = nullptr;
     size_t pend_words = 0;
     uint32_t grid_blocks = 0;
+    uint32_t lanes_override = 0;                // mcrt_set_lanes_per_pixel (0: automatic)
+    double* d_partial = nullptr;                // slice sums of the current pass, [slices][pixels][3]
+    size_t partial_bytes = 0;
     int refill_override = -1;                   // MCRT_REFILL (tuning knob): see RenderArgs::refill
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -695,6 +796,10 @@ int launch_unlit(mcrt_ctx* c, double* out)
     return c->big_in_lds ? launch_unlit_t<true, MCRT_ACCEL_OCTREE>(c, out) : launch_unlit_t<false, MCRT_ACCEL_OCTREE>(c, out);
 }
 
+// measured (profiles/r01_refill_sweep.txt): refilling pays when the image is walked from HBM/L2 (long,
+// exponentially distributed walks); with an LDS-resident image the extra shading passes cost more than they save
+uint32_t walk_refill(const mcrt_ctx* c) { return c->refill_override >= 0 ? (uint32_t)c->refill_override : (c->big_in_lds ? 0u : 32u); }
+
 int need_scene(mcrt_ctx* c, bool camera)
 {
     if (!c) return MCRT_ERR_INVALID;
@@ -755,6 +860,7 @@ int mcrt_destroy(mcrt_ctx* c)
     if (c->d_accum_own) (void)hipFree(c->d_accum_own);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_tile) (void)hipFree(c->d_tile);
+    if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_pend) (void)hipFree(c->d_pend);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -928,6 +1034,7 @@ int mcrt_trace_samples(mcrt_ctx* c, uint64_t n, const uint32_t* pixels, const ui
     a.view = c->view; a.cam = c->cam; a.pixels = dp.p; a.samples = ds.p; a.out = dout.p; a.counters = c->d_counters; a.pend = c->d_pend;
     a.n = n; a.max_depth = max_depth; a.seed = seed;
     a.ray_o = nullptr; a.ray_d = nullptr; a.ray_state = nullptr; a.ray_importance = nullptr;
+    a.refill = walk_refill(c);
     rc = launch_list(c, a);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(out, dout.p, n * 24, hipMemcpyDeviceToHost, c->stream));
@@ -962,6 +1069,7 @@ int mcrt_trace_rays(mcrt_ctx* c, uint64_t n, const float* origins, const float* 
     a.view = c->view; a.cam = c->cam; a.pixels = nullptr; a.samples = nullptr; a.out = dout.p; a.counters = c->d_counters; a.pend = c->d_pend;
     a.n = n; a.max_depth = max_depth; a.seed = 0;
     a.ray_o = dor.p; a.ray_d = ddi.p; a.ray_state = dst.p; a.ray_importance = dimp.p;
+    a.refill = walk_refill(c);
     rc = launch_list(c, a);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(out, dout.p, n * 24, hipMemcpyDeviceToHost, c->stream));
@@ -1031,17 +1139,51 @@ int mcrt_render(mcrt_ctx* c, uint32_t sample_begin, uint32_t sample_count, uint3
     RenderArgs a;
     a.view = c->view; a.cam = c->cam; a.accum = c->d_accum; a.tile_counter = c->d_tile; a.counters = c->d_counters; a.pend = c->d_pend;
     a.s_begin = sample_begin; a.s_count = sample_count; a.max_depth = max_depth;
-    // measured (profiles/r01_refill_sweep.txt): refilling pays when the image is walked from HBM/L2 (long,
-    // exponentially distributed walks); with an LDS-resident image the extra shading passes cost more than they save
-    a.refill = c->refill_override >= 0 ? (uint32_t)c->refill_override : (c->big_in_lds ? 0u : 32u);
+    a.refill = walk_refill(c);
     a.tiles_x = (c->cam.width + 7u) / 8u;
     a.tiles = a.tiles_x * ((c->cam.height + 7u) / 8u);
+    a.slices = c->lanes_override ? std::min<uint32_t>(c->lanes_override, sample_count) : mcrt_lanes_per_pixel(c->cam.width, c->cam.height, sample_count);
+    if ((uint64_t)a.tiles * 64u * a.slices > 0xFFFF0000ull) return fail(c, MCRT_ERR_LIMIT, "image too large for one pass");
+    a.items = a.tiles * 64u * a.slices;
+    a.partial = nullptr;
+    if (a.slices > 1) {
+        const size_t need = (size_t)a.slices * c->accum_pixels * 24;
+        if (need > c->partial_bytes) {
+            if (c->d_partial) { HIP_TRY(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_partial); c->d_partial = nullptr; c->partial_bytes = 0; }
+            HIP_TRY(c, hipMalloc(&c->d_partial, need));
+            c->partial_bytes = need;
+        }
+        a.partial = c->d_partial;
+    }
     a.seed = seed;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     rc = launch_render(c, a);
     if (rc) return rc;
+    if (a.slices > 1) {
+        const uint64_t values = (uint64_t)c->accum_pixels * 3;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((values + kBlock - 1) / kBlock, 65535);
+        hipLaunchKernelGGL(k_combine, dim3(blocks), dim3(kBlock), 0, c->stream, c->d_accum, (const double*)c->d_partial, values, a.slices);
+        HIP_TRY(c, hipGetLastError());
+    }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
+    return MCRT_OK;
+}
+
+uint32_t mcrt_lanes_per_pixel(uint32_t width, uint32_t height, uint32_t sample_count)
+{
+    // smallest power of two that brings pixels * slices to 2^20 work items, never more slices than samples
+    const uint64_t pixels = (uint64_t)width * height;
+    uint32_t l = 1;
+    while (l < 64u && pixels * l < (1ull << 20) && l * 2u <= sample_count) l *= 2u;
+    return l;
+}
+
+int mcrt_set_lanes_per_pixel(mcrt_ctx* c, uint32_t lanes)
+{
+    if (!c) return MCRT_ERR_INVALID;
+    if (lanes > 64u) return fail(c, MCRT_ERR_LIMIT, "at most 64 sample slices per pixel");
+    c->lanes_override = lanes;
     return MCRT_OK;
 }
 

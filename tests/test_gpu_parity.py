@@ -81,6 +81,18 @@ def test_per_sample_radiance(backend, pkg, oracle, scene_of, golden, name):
     assert abs(np.nanmean(got) - np.nanmean(ref)) < 0.02 * abs(np.nanmean(ref)) + 1e-6
 
 
+def _sliced_sum(rows, lanes):
+    """Sum of per-sample radiances in the order a render pass uses (include/mcrt.h, mcrt_lanes_per_pixel)."""
+    per = len(rows) // lanes
+    tot = None
+    for l in range(lanes):
+        part = np.zeros(3)
+        for row in rows[l * per:(len(rows) if l + 1 == lanes else (l + 1) * per)]:
+            part = part + row
+        tot = part if tot is None else tot + part
+    return tot
+
+
 def test_all_accel_modes_render_identically(backend, pkg, oracle, scene_of):
     flat = _upload(backend, pkg, scene_of, "config3")
     cam = oracle.camera(96, 64, 90.0, (0, 0, 5), (0, 0, 0))
@@ -93,7 +105,8 @@ def test_all_accel_modes_render_identically(backend, pkg, oracle, scene_of):
         backend.clear(); backend.render(0, 16, 100, SEED)
         assert np.array_equal(a, backend.read_accumulator())
     backend.set_accel(pkg.ACCEL_AUTO)
-    want, _ = oracle.render(oracle.scene(flat), cam, 0, 16, 100, SEED, threads=8, portable_math=True, forward_sum=True)
+    want, _ = oracle.render(oracle.scene(flat), cam, 0, 16, 100, SEED, threads=8, portable_math=True, forward_sum=True,
+                             lanes_per_pixel=backend.lanes_per_pixel(16))
     assert np.array_equal(a, want), f"max abs diff {np.abs(a - want).max()}"
 
 
@@ -165,8 +178,9 @@ def test_progressive_passes_and_sample_ranges(backend, pkg, scene_of, oracle):
     backend.clear(); backend.render(0, 32, 100, SEED); backend.render(32, 32, 100, SEED)
     got = backend.read_accumulator()
     sc = oracle.scene(flat)
-    want, _ = oracle.render(sc, cam, 0, 32, 100, SEED, threads=8, portable_math=True, forward_sum=True)
-    want, _ = oracle.render(sc, cam, 32, 32, 100, SEED, threads=8, portable_math=True, forward_sum=True, sums=want)
+    lanes = backend.lanes_per_pixel(32)
+    want, _ = oracle.render(sc, cam, 0, 32, 100, SEED, threads=8, portable_math=True, forward_sum=True, lanes_per_pixel=lanes)
+    want, _ = oracle.render(sc, cam, 32, 32, 100, SEED, threads=8, portable_math=True, forward_sum=True, sums=want, lanes_per_pixel=lanes)
     assert np.array_equal(got, want)
 
 
@@ -202,10 +216,16 @@ def test_full_size_properties_config1(backend, pkg, scene_of, oracle):
     sc = oracle.scene(flat)
     for p in px[:16]:
         s = oracle.trace_samples(sc, cam, np.full(64, p, np.uint32), np.arange(64, dtype=np.uint32), SEED, 100, portable_math=True, forward_sum=True)
-        tot = np.zeros(3)
-        for row in s:
-            tot = tot + row
-        assert np.array_equal(tot, a.reshape(-1, 3)[p])
+        assert np.array_equal(_sliced_sum(s, backend.lanes_per_pixel(64)), a.reshape(-1, 3)[p])
+    # the reference's own order (one slice): same samples, sums equal up to rounding, and exactly the forward sum
+    backend.set_lanes_per_pixel(1)
+    backend.clear(); backend.render(0, 64, 100, SEED)
+    one = backend.read_accumulator()
+    backend.set_lanes_per_pixel(0)
+    assert np.allclose(a, one, rtol=1e-12, atol=1e-12)
+    for p in px[:4]:
+        s = oracle.trace_samples(sc, cam, np.full(64, p, np.uint32), np.arange(64, dtype=np.uint32), SEED, 100, portable_math=True, forward_sum=True)
+        assert np.array_equal(_sliced_sum(s, 1), one.reshape(-1, 3)[p])
 
 
 def test_error_behaviour(pkg, scene_of):
@@ -237,12 +257,14 @@ def test_empty_and_ragged_inputs(backend, pkg, scene_of, oracle):
     backend.set_camera(cam)
     backend.clear(); backend.render(5, 3, 100, SEED)
     got = backend.read_accumulator()
-    want, _ = oracle.render(oracle.scene(scene_of("cornell")), cam, 5, 3, 100, SEED, threads=4, portable_math=True, forward_sum=True)
+    want, _ = oracle.render(oracle.scene(scene_of("cornell")), cam, 5, 3, 100, SEED, threads=4, portable_math=True, forward_sum=True,
+                             lanes_per_pixel=backend.lanes_per_pixel(3))
     assert np.array_equal(got, want)
     # depth 0: only emission of directly visible lights survives
     backend.clear(); backend.render(0, 2, 0, SEED)
     d0 = backend.read_accumulator()
-    want0, _ = oracle.render(oracle.scene(scene_of("cornell")), cam, 0, 2, 0, SEED, threads=4, portable_math=True, forward_sum=True)
+    want0, _ = oracle.render(oracle.scene(scene_of("cornell")), cam, 0, 2, 0, SEED, threads=4, portable_math=True, forward_sum=True,
+                              lanes_per_pixel=backend.lanes_per_pixel(2))
     assert np.array_equal(d0, want0)
 
 
