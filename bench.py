@@ -186,14 +186,16 @@ def main():
         "config": {
             "workload": f"{args.workload}: {scene_name} scene, {width}x{height}, {spp} spp per GPU, depth {DEPTH}, accel {args.accel}",
             "objects": int(len(flat.objects)), "triangles": int(len(flat.triangles)), "octree_nodes": int(info.node_count),
-            "scene_in_lds": bool(info.lds_resident), "parallelism": f"spp-sharded x{world}",
+            "scene_in_lds": bool(info.lds_resident), "lanes_per_pixel": be.lanes_per_pixel(spp), "parallelism": f"spp-sharded x{world}",
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-            "traffic": measured_traffic(args.workload),
+            "traffic": measured_traffic(args.workload) if args.accel == "auto" else None,
             "kernel": "k_render", "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_sample": round(bytes_per_sample, 2),
             "per_sample": {k: round(v / max(cnt["samples"], 1), 4) for k, v in cnt.items() if k != "samples"},
-            "note": "scene image is LDS-resident: the kernel is VALU/latency bound, HBM fraction is honest but small",
+            "note": ("scene image is read through scalar loads / LDS, not HBM: the kernel is VALU/latency bound, the HBM fraction is honest but small"
+                     if (info.lds_resident or len(flat.triangles) <= 256) else
+                     "scene image (%.0f MB) is walked from HBM/L2 by divergent lanes: bound by cache-line requests and lane divergence, not by streaming bandwidth" % (info.blob_bytes / 1e6)),
         },
     }
 

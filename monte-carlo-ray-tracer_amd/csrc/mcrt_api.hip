@@ -123,6 +123,18 @@ struct PendStack {
 
 struct RenderCounters { uint32_t samples, trace_calls, splits; };
 
+template <class PB> struct WalkStackFor {
+    typedef ScratchStack type;
+    static __device__ __forceinline__ void bind(type&, uint32_t*) {}
+};
+template <> struct WalkStackFor<GlbPtr> {
+    typedef LdsStack type;
+    static __device__ __forceinline__ void bind(type& st, uint32_t* lds) { st.col = (__attribute__((address_space(3))) uint32_t*)lds + threadIdx.x; }
+};
+// LDS words the kernels that trace paths need after the SMALL image (octree walk over an HBM-resident image)
+constexpr uint32_t kWalkLdsWords = LDS_STACK_ENTRIES * 3 * LDS_STACK_BLOCK;
+static_assert(LDS_STACK_BLOCK == kBlock, "LdsStack columns are one per thread of the block");
+
 enum : uint32_t { ST_NEW = 0, ST_TRACE = 1, ST_SHADOW = 2, ST_DONE = 3, ST_FETCH = 4 };
 
 // Explicit start of a TraceRay call (mcrt_trace_rays): ray, generator state and importance come from
@@ -142,7 +154,7 @@ struct ExplicitStart {
 template <class PS, class PB, int kAccel, bool kCount, class Work>
 __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, const CameraDev& cam, uint64_t seed, uint32_t max_depth,
                                            const PendStack& pend, bool keep_nonfinite, Counters& cn, RenderCounters& rc, Work& work,
-                                           uint32_t refill)
+                                           uint32_t refill, uint32_t* walk_lds)
 {
     D3 sum = dmk(0.0, 0.0, 0.0);
     uint32_t dropped = 0;
@@ -166,7 +178,9 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
     // and given their next ray while the others stay in mid-traversal.
     constexpr bool kWalk = (kAccel == MCRT_ACCEL_OCTREE);
     OctreeWalk<PS, PB, kCount> walk;
-    WalkStack walk_stack;
+    // walks through an HBM-resident image keep the top of their stack in LDS (walk_lds), see LdsStack
+    typename WalkStackFor<PB>::type walk_stack;
+    WalkStackFor<PB>::bind(walk_stack, walk_lds);
     bool walking = false;
     if (kWalk) walk.idle();
 
@@ -446,6 +460,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_render(const RenderArgs a)
     typename Mem::PS sm;
     typename Mem::PB big;
     Mem::open(a.view, smem, sm, big);
+    uint32_t* walk_lds = smem + ((a.view.small_words + 3u) & ~3u);     // used only by LdsStack (octree, image in HBM)
 
     PendStack pend;
     pend.base = a.pend;
@@ -463,10 +478,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_render(const RenderArgs a)
             base = (uint32_t)__shfl((int)base, 0);
             if (base >= a.items) break;                      // wave-uniform
             work.item = base + lane; work.armed = true;
-            trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, false, cn, rc, work, a.refill);
+            trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, false, cn, rc, work, a.refill, walk_lds);
         }
     } else {
-        trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, false, cn, rc, work, a.refill);
+        trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, false, cn, rc, work, a.refill, walk_lds);
     }
     if (work.dropped_total) atomicAdd(a.tile_counter + 1, work.dropped_total);
     if (kCount) flush_counters(a.counters, cn, rc);
@@ -536,6 +551,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_list(const ListArgs a)
     typename Mem::PS sm;
     typename Mem::PB big;
     Mem::open(a.view, smem, sm, big);
+    uint32_t* walk_lds = smem + ((a.view.small_words + 3u) & ~3u);     // used only by LdsStack (octree, image in HBM)
     PendStack pend;
     pend.base = a.pend;
     pend.entries = a.max_depth ? a.max_depth : 1u;
@@ -543,7 +559,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_list(const ListArgs a)
     Counters cn = { 0, 0, 0, 0, 0 };
     RenderCounters rc = { 0, 0, 0 };
     ListWork work = { a, pend.lane, (uint64_t)gridDim.x * blockDim.x, 0 };
-    trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, true, cn, rc, work, a.refill);
+    trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, true, cn, rc, work, a.refill, walk_lds);
     if (kCount) flush_counters(a.counters, cn, rc);
 }
 
@@ -697,7 +713,11 @@ int fail(mcrt_ctx* c, int code, const std::string& msg)
 
 int bind_device(mcrt_ctx* c) { HIP_TRY(c, hipSetDevice(c->device)); return MCRT_OK; }
 
-size_t lds_for(const mcrt_ctx* c) { return c->accel == MCRT_ACCEL_SCAN ? 0 : c->lds_bytes; }
+size_t lds_for(const mcrt_ctx* c)
+{
+    if (c->accel == MCRT_ACCEL_SCAN) return 0;
+    return c->lds_bytes + ((c->accel == MCRT_ACCEL_OCTREE && !c->big_in_lds) ? kWalkLdsWords * 4u : 0u);
+}
 
 void resolve_accel(mcrt_ctx* c)
 {

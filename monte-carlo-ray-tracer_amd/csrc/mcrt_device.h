@@ -359,9 +359,35 @@ MCRT_DEV Hit cast_brute(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters&
 // is tested), then its eight child slots fetched together (sixteen 16-byte loads in flight).
 // A stack entry is everything a visit needs (entry distance, child word, leaf-list index), copied out
 // of the child's record when the parent tested its box: a pop never re-reads the node.
-struct WalkStack {
-    float t[TRAVERSAL_STACK];
-    uint32_t cw[TRAVERSAL_STACK], leaf[TRAVERSAL_STACK];
+struct ScratchStack {
+    float t_[TRAVERSAL_STACK];
+    uint32_t cw_[TRAVERSAL_STACK], leaf_[TRAVERSAL_STACK];
+    MCRT_DEV void put(int i, float t, uint32_t cw, uint32_t leaf) { t_[i] = t; cw_[i] = cw; leaf_[i] = leaf; }
+    MCRT_DEV float t(int i) const { return t_[i]; }
+    MCRT_DEV void get(int i, uint32_t& cw, uint32_t& leaf) const { cw = cw_[i]; leaf = leaf_[i]; }
+};
+// The first LDS_STACK_ENTRIES entries live in LDS (field-major, one dword column per thread of the 256-thread
+// block: bank = thread id, conflict-free whatever the lanes' stack depths), the rest in scratch memory.  Scratch
+// is dword-interleaved per wavefront, so 64 lanes pushing at 64 different depths touch 64 different cache lines:
+// measured on the 1M-triangle scene, a scratch-only stack was most of the kernel's HBM traffic.
+constexpr int LDS_STACK_ENTRIES = 12;
+constexpr int LDS_STACK_BLOCK = 256;
+struct LdsStack {
+    __attribute__((address_space(3))) uint32_t* col;      // this thread's column
+    float t_[TRAVERSAL_STACK - LDS_STACK_ENTRIES];
+    uint32_t cw_[TRAVERSAL_STACK - LDS_STACK_ENTRIES], leaf_[TRAVERSAL_STACK - LDS_STACK_ENTRIES];
+    MCRT_DEV void put(int i, float t, uint32_t cw, uint32_t leaf)
+    {
+        if (i < LDS_STACK_ENTRIES) {
+            col[(i * 3 + 0) * LDS_STACK_BLOCK] = __float_as_uint(t); col[(i * 3 + 1) * LDS_STACK_BLOCK] = cw; col[(i * 3 + 2) * LDS_STACK_BLOCK] = leaf;
+        } else { t_[i - LDS_STACK_ENTRIES] = t; cw_[i - LDS_STACK_ENTRIES] = cw; leaf_[i - LDS_STACK_ENTRIES] = leaf; }
+    }
+    MCRT_DEV float t(int i) const { return i < LDS_STACK_ENTRIES ? __uint_as_float(col[(i * 3 + 0) * LDS_STACK_BLOCK]) : t_[i - LDS_STACK_ENTRIES]; }
+    MCRT_DEV void get(int i, uint32_t& cw, uint32_t& leaf) const
+    {
+        if (i < LDS_STACK_ENTRIES) { cw = col[(i * 3 + 1) * LDS_STACK_BLOCK]; leaf = col[(i * 3 + 2) * LDS_STACK_BLOCK]; }
+        else { cw = cw_[i - LDS_STACK_ENTRIES]; leaf = leaf_[i - LDS_STACK_ENTRIES]; }
+    }
 };
 
 template <class PS, class PB, bool kCount> struct OctreeWalk {
@@ -372,23 +398,23 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
     MCRT_DEV bool done() const { return sp == 0; }
     MCRT_DEV void idle() { sp = 0; gate_known = gate_pass = 0; best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax; }
 
-    MCRT_DEV void begin(PB big, const SceneView& v, WalkStack& st, Counters& cn)
+    template <class St> MCRT_DEV void begin(PB big, const SceneView& v, St& st, Counters& cn)
     {
         best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax;
         if (kCount) cn.rays++;
         gate_known = 0; gate_pass = 0;
         const U4 root = ld4(big + v.off_node, 4);
-        st.t[0] = 0.0f; st.cw[0] = root.z; st.leaf[0] = root.w; sp = 1;
+        st.put(0, 0.0f, root.z, root.w); sp = 1;
     }
 
     // One node visit.
-    MCRT_DEV void visit(PS sm, PB nodes, PB leaves, const SceneView& v, WalkStack& st, V3 o, V3 d, float ix, float iy, float iz, uint32_t flip,
+    template <class St> MCRT_DEV void visit(PS sm, PB nodes, PB leaves, const SceneView& v, St& st, V3 o, V3 d, float ix, float iy, float iz, uint32_t flip,
                         Counters& cn)
     {
         --sp;
-        if (st.t[sp] > best.t) return;            // entered behind the best hit so far
-        const uint32_t cw = st.cw[sp];
-        const uint32_t leaf = st.leaf[sp];
+        if (st.t(sp) > best.t) return;            // entered behind the best hit so far
+        uint32_t cw, leaf;
+        st.get(sp, cw, leaf);
         if (kCount) cn.nodes++;
 
         if (leaf != NO_REFS) {
@@ -454,14 +480,14 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
                 p = (__uint_as_float(lo.z) - o.z) * iz;
                 q = (__uint_as_float(hi.y) - o.z) * iz;
                 t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
-                if (exists && t0 <= t1) { st.t[sp] = t0; st.cw[sp] = hi.z; st.leaf[sp] = hi.w; ++sp; }
+                if (exists && t0 <= t1) { st.put(sp, t0, hi.z, hi.w); ++sp; }
             }
         }
     }
 
     // Advance every unfinished lane.  refill == 0: until all lanes of the wavefront are finished; otherwise
     // return once fewer than refill/64 of the lanes that came in unfinished are still walking.
-    MCRT_DEV void run(PS sm, PB big, const SceneView& v, WalkStack& st, V3 o, V3 d, Counters& cn, uint32_t refill)
+    template <class St> MCRT_DEV void run(PS sm, PB big, const SceneView& v, St& st, V3 o, V3 d, Counters& cn, uint32_t refill)
     {
         // Node culling is conservative (boxes are padded at build time), so fast reciprocals are fine here.
         const float ix = __frcp_rn(d.x), iy = __frcp_rn(d.y), iz = __frcp_rn(d.z);
@@ -483,7 +509,7 @@ template <class PS, class PB, bool kCount>
 MCRT_DEV Hit cast_octree(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters& cn)
 {
     OctreeWalk<PS, PB, kCount> w;
-    WalkStack st;
+    ScratchStack st;
     w.begin(big, v, st, cn);
     w.run(sm, big, v, st, o, d, cn, 0u);
     return w.best;
