@@ -218,7 +218,7 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
         Hit hit;
         if constexpr (kWalk) {
             if (!walking) { walk.begin(big, v, walk_stack, cn); walking = true; }
-            walk.run(sm, big, v, walk_stack, ro, rd, cn, refill);
+            walk.run(sm, big, v, walk_stack, ro, rd, cn, refill & 0xFFu, refill >> 8);
             if (!walk.done()) continue;                    // still in mid-traversal: nothing to shade yet
             walking = false;
             hit = walk.best;
@@ -691,6 +691,7 @@ struct mcrt_ctx {
     uint32_t lanes_override = 0;                // mcrt_set_lanes_per_pixel (0: automatic)
     double* d_partial = nullptr;                // slice sums of the current pass, [slices][pixels][3]
     size_t partial_bytes = 0;
+    int chunk_override = 0;                     // MCRT_LEAF_CHUNK (tuning knob)
     int refill_override = -1;                   // MCRT_REFILL (tuning knob): see RenderArgs::refill
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -818,7 +819,13 @@ int launch_unlit(mcrt_ctx* c, double* out)
 
 // measured (profiles/r01_refill_sweep.txt): refilling pays when the image is walked from HBM/L2 (long,
 // exponentially distributed walks); with an LDS-resident image the extra shading passes cost more than they save
-uint32_t walk_refill(const mcrt_ctx* c) { return c->refill_override >= 0 ? (uint32_t)c->refill_override : (c->big_in_lds ? 0u : 32u); }
+// bits 0..7: refill threshold; bits 8..: leaf records per visit (OctreeWalk::visit)
+uint32_t walk_refill(const mcrt_ctx* c)
+{
+    const uint32_t refill = c->refill_override >= 0 ? (uint32_t)c->refill_override : (c->big_in_lds ? 0u : 40u);
+    const uint32_t chunk = c->chunk_override > 0 ? (uint32_t)c->chunk_override : (c->big_in_lds ? 0xFFFFFFu : 4u);
+    return refill | (chunk << 8);
+}
 
 int need_scene(mcrt_ctx* c, bool camera)
 {
@@ -859,6 +866,7 @@ int mcrt_create(int device_id, mcrt_ctx** out_ctx)
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("MCRT_REFILL")) { int r = atoi(e); if (r >= 0 && r <= 64) c->refill_override = r; }
+    if (const char* e = getenv("MCRT_LEAF_CHUNK")) { int r = atoi(e); if (r > 0 && r < (1 << 20)) c->chunk_override = r; }
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     c->stream = c->own_stream;
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);

@@ -409,18 +409,29 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
 
     // One node visit.
     template <class St> MCRT_DEV void visit(PS sm, PB nodes, PB leaves, const SceneView& v, St& st, V3 o, V3 d, float ix, float iy, float iz, uint32_t flip,
-                        Counters& cn)
+                        uint32_t chunk, Counters& cn)
     {
-        --sp;
-        if (st.t(sp) > best.t) return;            // entered behind the best hit so far
+        // next entry that was not entered behind the best hit so far
+        float t_in;
+        do {
+            if (sp == 0) return;
+            --sp;
+            t_in = st.t(sp);
+        } while (t_in > best.t);
         uint32_t cw, leaf;
         st.get(sp, cw, leaf);
-        if (kCount) cn.nodes++;
+        const bool resumed = leaf != NO_REFS && (leaf & LEAF_RESUME);
+        if (resumed) leaf &= ~LEAF_RESUME;
+        else if (kCount) cn.nodes++;
 
         if (leaf != NO_REFS) {
+            // At most `chunk` records per visit: a lane with a long list re-queues the rest of it on top of its
+            // stack (and tests the node's children after the last record), so that the other lanes of the
+            // wavefront wait for `chunk` records, not for the longest list among 64 nodes.
             uint32_t r = leaf * LEAF_STRIDE;
             U4 a = ld4(leaves, r), b = ld4(leaves, r + 4), c = ld4(leaves, r + 8);
-            for (;;) {
+            bool finished = false;
+            for (uint32_t n = 0; n < chunk; ++n) {
                 r += LEAF_STRIDE;
                 // the next record of the stream is requested before this one is tested (the array ends in a pad record)
                 const U4 na = ld4(leaves, r), nb = ld4(leaves, r + 4), nc = ld4(leaves, r + 8);
@@ -453,8 +464,13 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
                 if (h && nearer(t, prim, best)) {
                     best.prim = prim; best.obj = obj; best.elem = prim - sm[orec + OBJ_FIRST_PRIM]; best.t = t;
                 }
-                if (c.y & REF_LAST) break;
+                if (c.y & REF_LAST) { finished = true; break; }
                 a = na; b = nb; c = nc;
+            }
+            if (!finished) {
+                st.put(sp, t_in, cw, (leaf + chunk) | LEAF_RESUME);
+                ++sp;
+                return;
             }
         }
 
@@ -487,7 +503,7 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
 
     // Advance every unfinished lane.  refill == 0: until all lanes of the wavefront are finished; otherwise
     // return once fewer than refill/64 of the lanes that came in unfinished are still walking.
-    template <class St> MCRT_DEV void run(PS sm, PB big, const SceneView& v, St& st, V3 o, V3 d, Counters& cn, uint32_t refill)
+    template <class St> MCRT_DEV void run(PS sm, PB big, const SceneView& v, St& st, V3 o, V3 d, Counters& cn, uint32_t refill, uint32_t chunk = 0xFFFFFFFFu)
     {
         // Node culling is conservative (boxes are padded at build time), so fast reciprocals are fine here.
         const float ix = __frcp_rn(d.x), iy = __frcp_rn(d.y), iz = __frcp_rn(d.z);
@@ -500,7 +516,7 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
         for (;;) {
             const uint32_t walking = (uint32_t)__popcll(__ballot(sp > 0));
             if (walking == 0 || walking < keep) break;
-            if (sp > 0) visit(sm, nodes, leaves, v, st, o, d, ix, iy, iz, flip, cn);
+            if (sp > 0) visit(sm, nodes, leaves, v, st, o, d, ix, iy, iz, flip, chunk, cn);
         }
     }
 };

@@ -74,6 +74,7 @@ enum : uint32_t {
     LEAF_STRIDE = 12
 };
 constexpr uint32_t LEAF_SPHERE = 0x80000000u;
+constexpr uint32_t LEAF_RESUME = 0x80000000u;  // traversal stack only: the entry resumes a leaf list part-way (index in the low bits)
 constexpr uint32_t NO_REFS = 0xFFFFFFFFu;
 constexpr uint32_t REF_LAST = 0x80000000u;   // set on the last reference of a node's list
 constexpr uint32_t MISS = 0xFFFFFFFFu;
