@@ -174,8 +174,6 @@ void camera_look_at(uint32_t width, uint32_t height, float fov_y_degrees, const 
     m[3][0] = -dot3(s, eye); m[3][1] = -dot3(u, eye); m[3][2] = dot3(f, eye);
     // glm::inverse(mat4): cofactor expansion, include/glm/detail/func_matrix.inl:294-352
     float c[6][3];   // the six 2x2 sub-determinant triples (Coef00..Coef23 grouped as Fac0..Fac5 uses them)
-    const int pairs[6][2] = { { 2, 3 }, { 1, 3 }, { 1, 2 }, { 0, 3 }, { 0, 2 }, { 0, 1 } };   // row pairs of each Fac
-    (void)pairs;
     auto det2 = [&](int ca, int ra, int cb, int rb) { return m[ca][ra] * m[cb][rb] - m[cb][ra] * m[ca][rb]; };
     // Fac0: rows (2,3); Fac1: rows (1,3); Fac2: rows (1,2); Fac3: rows (0,3); Fac4: rows (0,2); Fac5: rows (0,1);
     // each over column pairs (2,3), (1,3), (1,2)
