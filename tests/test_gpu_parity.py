@@ -93,6 +93,34 @@ def _sliced_sum(rows, lanes):
     return tot
 
 
+def test_render_through_hbm_resident_octree(backend, pkg, oracle, scene_of, golden):
+    """k_render with free-running lanes, the resumable walk and the LDS/scratch stack (2000-triangle mesh: the scene
+    image does not fit the LDS budget) equals the oracle's render bit for bit; so does a deep tree (leaf size 1,
+    depth 12) whose stacks overflow the LDS part, and sample counts that do not divide into the slices."""
+    flat = scene_of("config4_2k")
+    cam = oracle.camera(72, 40, 90.0, (0, 0, 5), (0, 0, 0))
+    sc = oracle.scene(flat)
+    for accel, spp in ((None, 7), (pkg.AccelParams(1, 12, 0.0), 5)):
+        backend.upload_scene(flat, accel)
+        assert not backend.octree_info().lds_resident
+        backend.set_camera(cam)
+        backend.clear(); backend.render(3, spp, 100, SEED)
+        got = backend.read_accumulator()
+        lanes = backend.lanes_per_pixel(spp)
+        assert lanes > 1 and spp % lanes != 0
+        want, _ = oracle.render(sc, cam, 3, spp, 100, SEED, threads=8, portable_math=True, forward_sum=True, lanes_per_pixel=lanes)
+        assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+    # per-sample radiance through the deep tree (k_trace_list, same walk)
+    g = golden("samples_config4_2k.npz")
+    backend.set_camera(pkg.abi.camera_from_numpy(g["camera"]))
+    n = 4000
+    got = backend.trace_samples(g["pixels"][:n], g["samples"][:n], int(g["seed"]), int(g["depth"]))
+    want = oracle.trace_samples(sc, pkg.abi.camera_from_numpy(g["camera"]), g["pixels"][:n], g["samples"][:n], int(g["seed"]), int(g["depth"]),
+                                portable_math=True, forward_sum=True)
+    same = (got.view(np.uint64) == want.view(np.uint64)).all(axis=1) | (np.isnan(got).any(axis=1) & np.isnan(want).any(axis=1))
+    assert same.all()
+
+
 def test_all_accel_modes_render_identically(backend, pkg, oracle, scene_of):
     flat = _upload(backend, pkg, scene_of, "config3")
     cam = oracle.camera(96, 64, 90.0, (0, 0, 5), (0, 0, 0))
