@@ -1200,10 +1200,12 @@ int mcrt_render(mcrt_ctx* c, uint32_t sample_begin, uint32_t sample_count, uint3
 
 uint32_t mcrt_lanes_per_pixel(uint32_t width, uint32_t height, uint32_t sample_count)
 {
-    // smallest power of two that brings pixels * slices to 2^20 work items, never more slices than samples
+    // smallest power of two that brings pixels * slices to 2^22 work items (16 tile-sized fetches per resident
+    // wavefront: measured, coarser items leave the GPU half empty while the last tiles finish), never more slices
+    // than samples
     const uint64_t pixels = (uint64_t)width * height;
     uint32_t l = 1;
-    while (l < 64u && pixels * l < (1ull << 20) && l * 2u <= sample_count) l *= 2u;
+    while (l < 64u && pixels * l < (1ull << 22) && l * 2u <= sample_count) l *= 2u;
     return l;
 }
 
