@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="config2_1024_256", choices=sorted(WORKLOADS))
-    ap.add_argument("--accel", default="auto", choices=["auto", "octree", "scan", "brute"])
+    ap.add_argument("--accel", default="auto", choices=["auto", "octree", "scan", "brute", "flat"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -112,7 +112,7 @@ def main():
     be.set_stream(stream.cuda_stream)
     be.upload_scene(flat)
     be.set_camera(cam)
-    be.set_accel({"auto": pkg.ACCEL_AUTO, "octree": pkg.ACCEL_OCTREE, "scan": pkg.ACCEL_SCAN, "brute": pkg.ACCEL_BRUTE}[args.accel])
+    be.set_accel({"auto": pkg.ACCEL_AUTO, "octree": pkg.ACCEL_OCTREE, "scan": pkg.ACCEL_SCAN, "brute": pkg.ACCEL_BRUTE, "flat": pkg.ACCEL_FLAT}[args.accel])
     accum = torch.zeros(height * width * 3, dtype=torch.float64, device="cuda")
     be.bind_accumulator(accum.data_ptr())
     from mcrt_amd import sharding

@@ -114,7 +114,7 @@ typedef struct mcrt_camera {
  *           lock-step pass;
  *   AUTO    SCAN when the scene has at most MCRT_SCAN_MAX_PRIMS primitives,
  *           OCTREE otherwise (default). */
-enum { MCRT_ACCEL_OCTREE = 0, MCRT_ACCEL_BRUTE = 1, MCRT_ACCEL_SCAN = 2, MCRT_ACCEL_AUTO = 3 };
+enum { MCRT_ACCEL_OCTREE = 0, MCRT_ACCEL_BRUTE = 1, MCRT_ACCEL_SCAN = 2, MCRT_ACCEL_AUTO = 3, MCRT_ACCEL_FLAT = 4 };
 #define MCRT_SCAN_MAX_PRIMS 256
 #define MCRT_SCAN_PAIR_LIMIT 65536   /* scenes with more triangles carry no scan records: SCAN is refused */
 

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import abi
 from .abi import (  # noqa: F401
-    ACCEL_AUTO, ACCEL_BRUTE, ACCEL_OCTREE, ACCEL_SCAN, TONEMAP_EXPOSURE, TONEMAP_NONE, TONEMAP_REINHARD, AccelParams, Camera, FlatScene, OctreeInfo,
+    ACCEL_AUTO, ACCEL_BRUTE, ACCEL_FLAT, ACCEL_OCTREE, ACCEL_SCAN, TONEMAP_EXPOSURE, TONEMAP_NONE, TONEMAP_REINHARD, AccelParams, Camera, FlatScene, OctreeInfo,
 )
 
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -13,7 +13,7 @@ OK = 0
 SURFACE_DIFFUSE, SURFACE_SPECULAR, SURFACE_DIFFUSE_SPECULAR, SURFACE_REFRACTIVE = 0, 1, 2, 3
 DIFFUSE_LAMBERTIAN, DIFFUSE_OREN_NAYAR = 0, 1
 OBJECT_SPHERE, OBJECT_MESH, OBJECT_LIGHT = 0, 1, 2
-ACCEL_OCTREE, ACCEL_BRUTE, ACCEL_SCAN, ACCEL_AUTO = 0, 1, 2, 3
+ACCEL_OCTREE, ACCEL_BRUTE, ACCEL_SCAN, ACCEL_AUTO, ACCEL_FLAT = 0, 1, 2, 3, 4
 TONEMAP_NONE, TONEMAP_REINHARD, TONEMAP_EXPOSURE = 0, 1, 2
 
 

@@ -76,6 +76,18 @@ template <bool kBigLds, int kAccel> struct SceneMem {
         big = big_ptr<kBigLds>(v, smem);
     }
 };
+// flat scan: object records through scalar loads, triangle records from the LDS copy of BIG
+template <bool kBigLds> struct SceneMem<kBigLds, MCRT_ACCEL_FLAT> {
+    typedef CstPtr PS;
+    typedef LdsPtr PB;
+    static __device__ __forceinline__ void open(const SceneView& v, uint32_t* smem, PS& sm, PB& big)
+    {
+        static_assert(kBigLds, "the flat scan needs the BIG image in LDS");
+        stage_scene<true>(v, smem);
+        sm = (CstPtr)v.small_img;
+        big = big_ptr<true>(v, smem);
+    }
+};
 template <bool kBigLds> struct SceneMem<kBigLds, MCRT_ACCEL_SCAN> {
     typedef CstPtr PS;
     typedef CstPtr PB;
@@ -468,7 +480,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_render(const RenderArgs a)
     pend.lane = blockIdx.x * blockDim.x + threadIdx.x;
     Counters cn = { 0, 0, 0, 0, 0 };
     RenderCounters rc = { 0, 0, 0 };
-    constexpr bool kRounds = kBigLds || kAccel == MCRT_ACCEL_SCAN;
+    constexpr bool kRounds = kBigLds || kAccel == MCRT_ACCEL_SCAN || kAccel == MCRT_ACCEL_FLAT;
     RenderWork<kRounds> work = { a, 0u, 0u, 0u, false };
     if (kRounds) {
         const uint32_t lane = threadIdx.x & 63u;
@@ -717,8 +729,12 @@ int bind_device(mcrt_ctx* c) { HIP_TRY(c, hipSetDevice(c->device)); return MCRT_
 size_t lds_for(const mcrt_ctx* c)
 {
     if (c->accel == MCRT_ACCEL_SCAN) return 0;
+    if (c->accel == MCRT_ACCEL_FLAT) return c->lds_bytes + 16u + (kBlock / 64) * FLAT_AREA_WORDS * 4u;
     return c->lds_bytes + ((c->accel == MCRT_ACCEL_OCTREE && !c->big_in_lds) ? kWalkLdsWords * 4u : 0u);
 }
+
+// the flat scan keeps BIG in LDS and packs (object, element) into 32 bits
+bool flat_ok(const mcrt_ctx* c) { return c->big_in_lds && c->view.ntri < (1u << FLAT_ELEM_BITS) && c->view.nobj <= 64u; }
 
 void resolve_accel(mcrt_ctx* c)
 {
@@ -796,6 +812,10 @@ template <bool kBigLds, int kAccel> int launch_unlit_t(mcrt_ctx* c, double* out)
             if ((c)->counting) return CALL_<false, MCRT_ACCEL_SCAN, true>(__VA_ARGS__);                                \
             return CALL_<false, MCRT_ACCEL_SCAN, false>(__VA_ARGS__);                                                   \
         }                                                                                                               \
+        if ((c)->accel == MCRT_ACCEL_FLAT) {                                                                            \
+            if ((c)->counting) return CALL_<true, MCRT_ACCEL_FLAT, true>(__VA_ARGS__);                                 \
+            return CALL_<true, MCRT_ACCEL_FLAT, false>(__VA_ARGS__);                                                    \
+        }                                                                                                               \
         if ((c)->accel == MCRT_ACCEL_BRUTE) {                                                                           \
             if ((c)->counting) return lds_ ? CALL_<true, MCRT_ACCEL_BRUTE, true>(__VA_ARGS__) : CALL_<false, MCRT_ACCEL_BRUTE, true>(__VA_ARGS__);   \
             return lds_ ? CALL_<true, MCRT_ACCEL_BRUTE, false>(__VA_ARGS__) : CALL_<false, MCRT_ACCEL_BRUTE, false>(__VA_ARGS__);                    \
@@ -813,6 +833,7 @@ int launch_intersect(mcrt_ctx* c, uint64_t n, const float* o, const float* d, in
 int launch_unlit(mcrt_ctx* c, double* out)
 {
     if (c->accel == MCRT_ACCEL_SCAN) return launch_unlit_t<false, MCRT_ACCEL_SCAN>(c, out);
+    if (c->accel == MCRT_ACCEL_FLAT) return launch_unlit_t<true, MCRT_ACCEL_FLAT>(c, out);
     if (c->accel == MCRT_ACCEL_BRUTE) return c->big_in_lds ? launch_unlit_t<true, MCRT_ACCEL_BRUTE>(c, out) : launch_unlit_t<false, MCRT_ACCEL_BRUTE>(c, out);
     return c->big_in_lds ? launch_unlit_t<true, MCRT_ACCEL_OCTREE>(c, out) : launch_unlit_t<false, MCRT_ACCEL_OCTREE>(c, out);
 }
@@ -934,6 +955,7 @@ int mcrt_upload_scene(mcrt_ctx* c, const mcrt_scene_desc* scene, const mcrt_acce
     c->lds_bytes = c->big_in_lds ? all_bytes : small_bytes;
     c->have_scene = true;
     if (c->accel_request == MCRT_ACCEL_SCAN && !c->view.has_pairs) c->accel_request = MCRT_ACCEL_AUTO;   // scan cannot serve this scene
+    if (c->accel_request == MCRT_ACCEL_FLAT && !flat_ok(c)) c->accel_request = MCRT_ACCEL_AUTO;
     resolve_accel(c);
     return MCRT_OK;
 }
@@ -978,7 +1000,8 @@ int mcrt_camera_look_at(uint32_t width, uint32_t height, float fov_y_degrees, co
 int mcrt_set_accel(mcrt_ctx* c, int mode)
 {
     if (!c) return MCRT_ERR_INVALID;
-    if (mode < MCRT_ACCEL_OCTREE || mode > MCRT_ACCEL_AUTO) return fail(c, MCRT_ERR_INVALID, "unknown accel mode");
+    if (mode < MCRT_ACCEL_OCTREE || mode > MCRT_ACCEL_FLAT) return fail(c, MCRT_ERR_INVALID, "unknown accel mode");
+    if (mode == MCRT_ACCEL_FLAT && c->have_scene && !flat_ok(c)) return fail(c, MCRT_ERR_LIMIT, "scene too large for the flat scan (LDS-resident scenes only)");
     if (mode == MCRT_ACCEL_SCAN && c->have_scene && !c->view.has_pairs)
         return fail(c, MCRT_ERR_LIMIT, "scene has more than MCRT_SCAN_PAIR_LIMIT triangles: no scan records, use the octree");
     c->accel_request = mode;

@@ -683,11 +683,134 @@ MCRT_DEV Hit cast_scan(CstPtr sm, CstPtr big, const SceneView& v, V3 o, V3 d, Co
     return best;
 }
 
+// ---------------------------------------------------------------- wave-cooperative flat scan
+// Same candidate set and same answers as cast_scan, different division of labour.  In cast_scan every
+// lane of the wavefront sits through every triangle of every mesh that ANY lane's ray may touch; with 64
+// incoherent rays that is all of them, while a single ray passes the gates of a fifth of the triangles
+// (measured: 31 % active lanes).  Here the (ray, triangle) pairs that actually need testing - for each
+// mesh, the rays that passed its gate times its triangles - are laid end to end and dealt out evenly
+// to the lanes: lane r takes pairs r, r + n, r + 2n ... (n = active lanes), fetches "its" ray from a
+// per-wavefront LDS table, tests one triangle and, on a hit, merges (t, object, element) into the ray's
+// slot with one 64-bit LDS atomic min - the key order IS the reference's tie-break (nearest, then earlier
+// object, then earlier triangle: source/scene.cpp:73, source/objects/mesh.cpp:22).
+constexpr uint32_t FLAT_AREA_WORDS = 64u * 12u;     // per wavefront: 64 rays x 8 words, 64 keys x 2 words, 64 list entries x 1 word (+ pad)
+constexpr uint32_t FLAT_ELEM_BITS = 20;
+typedef __attribute__((address_space(3))) uint32_t* LdsRw;
+
+MCRT_DEV void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool kCount>
+MCRT_DEV Hit cast_flat(CstPtr sm, LdsPtr big, LdsRw area, const SceneView& v, V3 o, V3 d, Counters& cn)
+{
+    if (kCount) cn.rays++;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t act = __ballot(1);
+    const uint32_t nact = (uint32_t)__popcll(act);
+    const uint64_t below = (1ull << lane) - 1ull;
+    const uint32_t rank = (uint32_t)__popcll(act & below);
+    LdsRw rays = area;                       // [64][8]
+    LdsRw keys = area + 64u * 8u;            // [64] u64
+    LdsRw list = area + 64u * 10u;           // [64]
+    {
+        U4 a, b;
+        a.x = __float_as_uint(o.x); a.y = __float_as_uint(o.y); a.z = __float_as_uint(o.z); a.w = 0u;
+        b.x = __float_as_uint(d.x); b.y = __float_as_uint(d.y); b.z = __float_as_uint(d.z); b.w = 0u;
+        *(__attribute__((address_space(3))) U4*)(rays + lane * 8u) = a;
+        *(__attribute__((address_space(3))) U4*)(rays + lane * 8u + 4u) = b;
+        *(__attribute__((address_space(3))) unsigned long long*)(keys + lane * 2u) = 0x7F7FFFFFFFFFFFFFull;   // (FLT_MAX, MISS)
+    }
+    Hit best; best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax;     // spheres: tested by the ray's own lane
+    const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    const float tiny = 1.0e-20f;
+    const bool exact_only = (d.x != 0.0f && fabsf(d.x) < tiny) || (d.y != 0.0f && fabsf(d.y) < tiny) || (d.z != 0.0f && fabsf(d.z) < tiny);
+    CstPtr rec = sm + v.off_obj;
+    for (uint32_t i = 0; i < v.nobj; ++i, rec += OBJ_STRIDE) {
+        const U8 head = *(const __attribute__((address_space(4))) U8*)rec;   // kind, first_tri, tri_count, first_prim, radius, pos
+        if (head.s0 == MCRT_OBJECT_SPHERE) {
+            // SphereObject::Intersects, source/objects/sphere.h:16-52
+            if (kCount) cn.spheres++;
+            const float radius = __uint_as_float(head.s4);
+            if (!(radius < kFltEpsilon)) {
+                const float radiusSq = radius * radius;
+                const V3 L = mk(__uint_as_float(head.s5), __uint_as_float(head.s6), __uint_as_float(head.s7)) - o;
+                const float tca = dot(L, d);
+                const float distanceSq = dot(L, L) - tca * tca;
+                if (!(tca < 0) && !(distanceSq > radiusSq)) {
+                    const float thc = sqrtf(radiusSq - distanceSq);
+                    float t0 = tca - thc, t1 = tca + thc;
+                    if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
+                    if (t0 < 0) t0 = t1;
+                    if (!(t0 < 0) && t0 < best.t) { best.obj = i; best.elem = 0; best.t = t0; }
+                }
+            }
+            continue;
+        }
+        if (kCount) cn.gates++;
+        const bool pass = gate_hit_fast(rec, o, d, inv, exact_only);
+        const uint64_t mask = __ballot(pass);
+        if (mask == 0ull) continue;                                   // nobody in the wave needs this mesh
+        const uint32_t count = head.s2, first = head.s1;
+        if (count == 0u) continue;
+        if (pass) list[(uint32_t)__popcll(mask & below)] = lane;       // compact the passing rays
+        wave_sync();
+        const uint32_t total = (uint32_t)__popcll(mask) * count;
+        const float inv_count = 1.0f / (float)count;
+        for (uint32_t w = rank; w < total; w += nact) {
+            // slot = w / count, k = w % count  (count is wave-uniform, w < 2^24: one float multiply and a fix-up)
+            uint32_t slot = (uint32_t)((float)w * inv_count);
+            if (slot * count > w) --slot;
+            else if ((slot + 1u) * count <= w) ++slot;
+            const uint32_t k = w - slot * count;
+            const uint32_t src = list[slot];
+            const U4 ra = *(const __attribute__((address_space(3))) U4*)(rays + src * 8u);
+            const U4 rb = *(const __attribute__((address_space(3))) U4*)(rays + src * 8u + 4u);
+            const V3 ro = mk(__uint_as_float(ra.x), __uint_as_float(ra.y), __uint_as_float(ra.z));
+            const V3 rd = mk(__uint_as_float(rb.x), __uint_as_float(rb.y), __uint_as_float(rb.z));
+            const TriRec tr = load_tri(big, v.off_tri + (first + k) * TRI_STRIDE);
+            if (kCount) cn.tris++;
+            // Triangle::Intersects, source/core/triangle.h:31-60
+            const V3 h = cross(rd, tr.e2);
+            const float a = dot(tr.e1, h);
+            const V3 sv = ro - tr.v0;
+            const float x = dot(sv, h);
+            const V3 q = cross(sv, tr.e1);
+            const float y = dot(rd, q);
+            const float z = dot(tr.e2, q);
+            float t;
+            if (tri_maybe(a, x, y, z, kFltMax) && tri_exact_tail(a, x, y, z, kFltMax, t)) {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((i << FLAT_ELEM_BITS) | k);
+                atomicMin((unsigned long long*)(keys + src * 2u), key);
+            }
+        }
+        wave_sync();                                                  // the list is reused by the next mesh
+    }
+    const unsigned long long key = *(__attribute__((address_space(3))) unsigned long long*)(keys + lane * 2u);
+    const float tm = __uint_as_float((uint32_t)(key >> 32));
+    const uint32_t om = ((uint32_t)key) >> FLAT_ELEM_BITS, em = ((uint32_t)key) & ((1u << FLAT_ELEM_BITS) - 1u);
+    // nearest, ties to the earlier object (a mesh and a sphere are never the same object)
+    if ((uint32_t)key != MISS && (tm < best.t || (tm == best.t && om < best.obj))) { best.obj = om; best.elem = em; best.t = tm; }
+    if (best.obj != MISS) best.prim = sm[v.off_obj + best.obj * OBJ_STRIDE + OBJ_FIRST_PRIM] + best.elem;
+    wave_sync();                                                      // rays/keys are rewritten by the next query
+    return best;
+}
+
 template <int kAccel, class PS, class PB, bool kCount> struct Caster {
     static MCRT_DEV Hit run(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters& cn)
     {
         if (kAccel == MCRT_ACCEL_BRUTE) return cast_brute<PS, PB, kCount>(sm, big, v, o, d, cn);
         return cast_octree<PS, PB, kCount>(sm, big, v, o, d, cn);
+    }
+};
+template <bool kCount> struct Caster<MCRT_ACCEL_FLAT, CstPtr, LdsPtr, kCount> {
+    static MCRT_DEV Hit run(CstPtr sm, LdsPtr big, const SceneView& v, V3 o, V3 d, Counters& cn)
+    {
+        // the per-wavefront work area follows the staged BIG image in LDS
+        LdsRw area = (LdsRw)(big + ((v.big_words + 3u) & ~3u)) + (threadIdx.x >> 6) * FLAT_AREA_WORDS;
+        return cast_flat<kCount>(sm, big, area, v, o, d, cn);
     }
 };
 template <bool kCount> struct Caster<MCRT_ACCEL_SCAN, CstPtr, CstPtr, kCount> {

@@ -33,12 +33,14 @@ def test_camera_rays_bit_exact(backend, pkg, golden, tag):
     assert np.array_equal(d.view(np.uint32), g["dirs"].view(np.uint32))
 
 
-@pytest.mark.parametrize("accel", ["octree", "brute", "scan"])
+@pytest.mark.parametrize("accel", ["octree", "brute", "scan", "flat"])
 @pytest.mark.parametrize("name", SCENES)
 def test_hits_bit_exact_vs_reference(backend, pkg, scene_of, golden, name, accel):
     """Fixed-ray queries: hit object, element index AND distance equal the reference's Scene::IntersectRay."""
     _upload(backend, pkg, scene_of, name)
-    backend.set_accel({"octree": pkg.ACCEL_OCTREE, "brute": pkg.ACCEL_BRUTE, "scan": pkg.ACCEL_SCAN}[accel])
+    if accel == "flat" and not backend.octree_info().lds_resident:
+        pytest.skip("the flat scan serves LDS-resident scenes")
+    backend.set_accel({"octree": pkg.ACCEL_OCTREE, "brute": pkg.ACCEL_BRUTE, "scan": pkg.ACCEL_SCAN, "flat": pkg.ACCEL_FLAT}[accel])
     g = golden(f"hits_{name}.npz")
     obj, elem, t = backend.intersect(g["origins"], g["dirs"])
     backend.set_accel(pkg.ACCEL_AUTO)
@@ -128,7 +130,7 @@ def test_all_accel_modes_render_identically(backend, pkg, oracle, scene_of):
     backend.set_accel(pkg.ACCEL_BRUTE)
     backend.clear(); backend.render(0, 16, 100, SEED)
     a = backend.read_accumulator()
-    for mode in (pkg.ACCEL_OCTREE, pkg.ACCEL_SCAN):
+    for mode in (pkg.ACCEL_OCTREE, pkg.ACCEL_SCAN, pkg.ACCEL_FLAT):
         backend.set_accel(mode)
         backend.clear(); backend.render(0, 16, 100, SEED)
         assert np.array_equal(a, backend.read_accumulator())
