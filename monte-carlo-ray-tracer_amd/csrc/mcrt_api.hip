@@ -734,7 +734,7 @@ size_t lds_for(const mcrt_ctx* c)
 }
 
 // the flat scan keeps BIG in LDS and packs (object, element) into 32 bits
-bool flat_ok(const mcrt_ctx* c) { return c->big_in_lds && c->view.ntri < (1u << FLAT_ELEM_BITS) && c->view.nobj <= 64u; }
+bool flat_ok(const mcrt_ctx* c) { return c->big_in_lds && c->view.has_pairs && c->view.ntri < (1u << FLAT_ELEM_BITS) && c->view.nobj <= 64u; }
 
 void resolve_accel(mcrt_ctx* c)
 {

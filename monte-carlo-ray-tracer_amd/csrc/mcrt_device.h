@@ -695,6 +695,7 @@ MCRT_DEV Hit cast_scan(CstPtr sm, CstPtr big, const SceneView& v, V3 o, V3 d, Co
 // object, then earlier triangle: source/scene.cpp:73, source/objects/mesh.cpp:22).
 constexpr uint32_t FLAT_AREA_WORDS = 64u * 12u;     // per wavefront: 64 rays x 8 words, 64 keys x 2 words, 64 list entries x 1 word (+ pad)
 constexpr uint32_t FLAT_ELEM_BITS = 20;
+constexpr uint32_t FLAT_MIN_SCAN_LANES = 24;
 typedef __attribute__((address_space(3))) uint32_t* LdsRw;
 
 MCRT_DEV void wave_sync()
@@ -723,7 +724,7 @@ MCRT_DEV Hit cast_flat(CstPtr sm, LdsPtr big, LdsRw area, const SceneView& v, V3
         *(__attribute__((address_space(3))) U4*)(rays + lane * 8u + 4u) = b;
         *(__attribute__((address_space(3))) unsigned long long*)(keys + lane * 2u) = 0x7F7FFFFFFFFFFFFFull;   // (FLT_MAX, MISS)
     }
-    Hit best; best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax;     // spheres: tested by the ray's own lane
+    Hit best; best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax;     // spheres and widely needed meshes: tested by the ray's own lane
     const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     const float tiny = 1.0e-20f;
     const bool exact_only = (d.x != 0.0f && fabsf(d.x) < tiny) || (d.y != 0.0f && fabsf(d.y) < tiny) || (d.z != 0.0f && fabsf(d.z) < tiny);
@@ -755,6 +756,33 @@ MCRT_DEV Hit cast_flat(CstPtr sm, LdsPtr big, LdsRw area, const SceneView& v, V3
         if (mask == 0ull) continue;                                   // nobody in the wave needs this mesh
         const uint32_t count = head.s2, first = head.s1;
         if (count == 0u) continue;
+        if ((uint32_t)__popcll(mask) >= FLAT_MIN_SCAN_LANES) {
+            // Most of the wavefront needs this mesh (the walls of a closed room): the lock-step pair loop of
+            // cast_scan costs 38 instructions per lane and triangle against ~100 for a dealt pair, so it wins
+            // from about 24 passing lanes up.
+            if (pass) {
+                CstPtr pr = (CstPtr)v.big_img + v.off_pair + (size_t)rec[OBJ_FIRST_PAIR] * PAIR_STRIDE;
+                for (uint32_t k = 0; k < count; k += 2, pr += PAIR_STRIDE) {
+                    const U16 c0 = *(const __attribute__((address_space(4))) U16*)pr;
+                    const U4 c1 = *(const __attribute__((address_space(4))) U4*)(pr + 16);
+                    const F2 v0x = f2(c0.s0, c0.s1), v0y = f2(c0.s2, c0.s3), v0z = f2(c0.s4, c0.s5);
+                    const F2 e1x = f2(c0.s6, c0.s7), e1y = f2(c0.s8, c0.s9), e1z = f2(c0.sa, c0.sb);
+                    const F2 e2x = f2(c0.sc, c0.sd), e2y = f2(c0.se, c0.sf), e2z = f2(c1.x, c1.y);
+                    const F2 hx = d.y * e2z - e2y * d.z, hy = d.z * e2x - e2z * d.x, hz = d.x * e2y - e2x * d.y;   // cross(d, edge2)
+                    const F2 a = dot2(e1x, e1y, e1z, hx, hy, hz);
+                    const F2 sx = o.x - v0x, sy = o.y - v0y, sz = o.z - v0z;
+                    const F2 x = dot2(sx, sy, sz, hx, hy, hz);
+                    const F2 qx = sy * e1z - e1y * sz, qy = sz * e1x - e1z * sx, qz = sx * e1y - e1x * sy;          // cross(s, edge1)
+                    const F2 y = dot2(F2(d.x), F2(d.y), F2(d.z), qx, qy, qz);
+                    const F2 z = dot2(e2x, e2y, e2z, qx, qy, qz);
+                    float t;
+                    if (kCount) cn.tris += (k + 1 < count) ? 2u : 1u;
+                    if (tri_maybe(a.x, x.x, y.x, z.x, best.t) && tri_exact_tail(a.x, x.x, y.x, z.x, best.t, t)) { best.obj = i; best.elem = k; best.t = t; }
+                    if (tri_maybe(a.y, x.y, y.y, z.y, best.t) && tri_exact_tail(a.y, x.y, y.y, z.y, best.t, t)) { best.obj = i; best.elem = k + 1; best.t = t; }
+                }
+            }
+            continue;
+        }
         if (pass) list[(uint32_t)__popcll(mask & below)] = lane;       // compact the passing rays
         wave_sync();
         const uint32_t total = (uint32_t)__popcll(mask) * count;
