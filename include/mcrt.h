@@ -112,7 +112,13 @@ typedef struct mcrt_camera {
  *           through scalar loads - the fast path for scenes of a few hundred
  *           primitives, where 64 lanes on 64 different tree paths lose to one
  *           lock-step pass;
- *   AUTO    SCAN when the scene has at most MCRT_SCAN_MAX_PRIMS primitives,
+ *   FLAT    SCAN with the work dealt out: a mesh most of the wavefront needs
+ *           (>= 24 lanes pass its gate) is walked in lock step as in SCAN; for
+ *           the others the (ray, triangle) pairs that need testing are laid
+ *           end to end and dealt evenly to the 64 lanes through LDS, results
+ *           merged per ray with a 64-bit atomic min on (t, object, element) -
+ *           the reference's tie-break order.  LDS-resident scenes only;
+ *   AUTO    FLAT when the scene has at most MCRT_SCAN_MAX_PRIMS primitives,
  *           OCTREE otherwise (default). */
 enum { MCRT_ACCEL_OCTREE = 0, MCRT_ACCEL_BRUTE = 1, MCRT_ACCEL_SCAN = 2, MCRT_ACCEL_AUTO = 3, MCRT_ACCEL_FLAT = 4 };
 #define MCRT_SCAN_MAX_PRIMS 256

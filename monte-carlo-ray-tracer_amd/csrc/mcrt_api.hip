@@ -739,7 +739,8 @@ bool flat_ok(const mcrt_ctx* c) { return c->big_in_lds && c->view.has_pairs && c
 void resolve_accel(mcrt_ctx* c)
 {
     c->accel = c->accel_request;
-    if (c->accel == MCRT_ACCEL_AUTO) c->accel = (c->have_scene && c->view.nprim <= MCRT_SCAN_MAX_PRIMS) ? MCRT_ACCEL_SCAN : MCRT_ACCEL_OCTREE;
+    if (c->accel == MCRT_ACCEL_AUTO)
+        c->accel = (c->have_scene && c->view.nprim <= MCRT_SCAN_MAX_PRIMS) ? (flat_ok(c) ? MCRT_ACCEL_FLAT : MCRT_ACCEL_SCAN) : MCRT_ACCEL_OCTREE;
 }
 
 // persistent grid: enough 256-lane workgroups to fill every CU at the occupancy the kernel can reach

@@ -695,7 +695,10 @@ MCRT_DEV Hit cast_scan(CstPtr sm, CstPtr big, const SceneView& v, V3 o, V3 d, Co
 // object, then earlier triangle: source/scene.cpp:73, source/objects/mesh.cpp:22).
 constexpr uint32_t FLAT_AREA_WORDS = 64u * 12u;     // per wavefront: 64 rays x 8 words, 64 keys x 2 words, 64 list entries x 1 word (+ pad)
 constexpr uint32_t FLAT_ELEM_BITS = 20;
-constexpr uint32_t FLAT_MIN_SCAN_LANES = 24;
+#ifndef MCRT_FLAT_MIN
+#define MCRT_FLAT_MIN 24
+#endif
+constexpr uint32_t FLAT_MIN_SCAN_LANES = MCRT_FLAT_MIN;
 typedef __attribute__((address_space(3))) uint32_t* LdsRw;
 
 MCRT_DEV void wave_sync()
