@@ -380,7 +380,8 @@ struct RenderArgs {
     unsigned long long* counters;   // 8 x u64 (kCount builds)
     uint32_t* pend;
     uint32_t s_begin, s_count, max_depth;
-    uint32_t tiles_x, tiles;    // 8x8 pixel tiles
+    uint32_t tiles_x, tiles;    // pixel tiles of (64 >> wave_slices_log2) pixels
+    uint32_t wave_slices_log2;  // slices of one pixel that share a wavefront
     uint32_t slices;            // sample slices per pixel (mcrt_lanes_per_pixel)
     uint32_t items;             // tiles * 64 * slices
     uint32_t refill;            // octree walk: leave the walk loop below refill/64 of the lanes that entered (0: never)
@@ -419,10 +420,14 @@ template <bool kRounds> struct RenderWork {
     bool armed;
     __device__ __forceinline__ bool decode(uint32_t i, uint32_t& pixel, uint32_t& s_begin, uint32_t& s_count)
     {
+        // a wavefront's 64 items: (64 >> wave_slices_log2) pixels of one small tile x (1 << wave_slices_log2) slices
         const uint32_t t = i >> 6, within = i & 63u;
         const uint32_t tile = t % a.tiles;
-        slice = t / a.tiles;
-        const uint32_t x = (tile % a.tiles_x) * 8u + (within & 7u), y = (tile / a.tiles_x) * 8u + (within >> 3);
+        const uint32_t log_p = 6u - a.wave_slices_log2;
+        const uint32_t pix = within & ((1u << log_p) - 1u);
+        slice = ((t / a.tiles) << a.wave_slices_log2) + (within >> log_p);
+        const uint32_t log_w = (log_p + 1u) >> 1, log_h = log_p >> 1;
+        const uint32_t x = ((tile % a.tiles_x) << log_w) + (pix & ((1u << log_w) - 1u)), y = ((tile / a.tiles_x) << log_h) + (pix >> log_w);
         if (x >= a.cam.width || y >= a.cam.height) return false;
         pixel = y * a.cam.width + x;
         const uint32_t per = a.s_count / a.slices;
@@ -1192,11 +1197,22 @@ int mcrt_render(mcrt_ctx* c, uint32_t sample_begin, uint32_t sample_count, uint3
     a.view = c->view; a.cam = c->cam; a.accum = c->d_accum; a.tile_counter = c->d_tile; a.counters = c->d_counters; a.pend = c->d_pend;
     a.s_begin = sample_begin; a.s_count = sample_count; a.max_depth = max_depth;
     a.refill = walk_refill(c);
-    a.tiles_x = (c->cam.width + 7u) / 8u;
-    a.tiles = a.tiles_x * ((c->cam.height + 7u) / 8u);
     a.slices = c->lanes_override ? std::min<uint32_t>(c->lanes_override, sample_count) : mcrt_lanes_per_pixel(c->cam.width, c->cam.height, sample_count);
-    if ((uint64_t)a.tiles * 64u * a.slices > 0xFFFF0000ull) return fail(c, MCRT_ERR_LIMIT, "image too large for one pass");
-    a.items = a.tiles * 64u * a.slices;
+    {
+        // the slices of a pixel share a wavefront (4 slices: 4x4 pixels x 4 slices): a smaller pixel footprint per
+        // wavefront keeps its primary rays, first hits and shading branches together (+6..8 % measured);
+        // MCRT_WAVE_SLICES overrides (tuning knob)
+        uint32_t ws = 64;
+        if (const char* e = getenv("MCRT_WAVE_SLICES")) ws = (uint32_t)atoi(e);
+        uint32_t lg = 0;
+        while ((2u << lg) <= ws && (2u << lg) <= a.slices && a.slices % (2u << lg) == 0 && lg < 6) ++lg;
+        a.wave_slices_log2 = lg;
+        const uint32_t log_p = 6u - lg, tw = 1u << ((log_p + 1u) >> 1), th = 1u << (log_p >> 1);
+        a.tiles_x = (c->cam.width + tw - 1u) / tw;
+        a.tiles = a.tiles_x * ((c->cam.height + th - 1u) / th);
+    }
+    if ((uint64_t)a.tiles * 64u * (a.slices >> a.wave_slices_log2) > 0xFFFF0000ull) return fail(c, MCRT_ERR_LIMIT, "image too large for one pass");
+    a.items = a.tiles * 64u * (a.slices >> a.wave_slices_log2);
     a.partial = nullptr;
     if (a.slices > 1) {
         const size_t need = (size_t)a.slices * c->accum_pixels * 24;

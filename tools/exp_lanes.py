@@ -17,5 +17,5 @@ def run(scene, w, h, spp, lanes):
         be.clear(); be.render(0, spp, 100, SEED); ms.append(be.last_render_ms())
     be.close()
     return w * h * spp / (min(ms) * 1e-3) / 1e6
-for scene, w, h, spp in (("config2", 1024, 1024, 256), ("cornell", 1024, 1024, 256), ("cornell", 2048, 2048, 64), ("cornell", 3840, 2160, 64)):
-    print(scene, w, h, spp, {l: round(run(scene, w, h, spp, l)) for l in (1, 2, 4, 16)}, flush=True)
+for scene, w, h, spp in (("cornell", 512, 512, 64), ("config2", 1024, 1024, 256), ("cornell", 1024, 1024, 256), ("cornell", 2048, 2048, 64), ("config2", 3840, 2160, 64)):
+    print(scene, w, h, spp, {l: round(run(scene, w, h, spp, l)) for l in (1, 2, 4, 8, 16, 64)}, flush=True)
