@@ -245,7 +245,8 @@ int mcrt_render(mcrt_ctx* ctx, uint32_t sample_begin, uint32_t sample_count,
 /* Summation order of one mcrt_render pass.  The reference adds a pixel's
  * samples one by one in sample order (PixelBuffer::Accumulate,
  * source/core/pixelbuffer.cpp:39-46).  A pass does the same unless the image
- * has too few pixels (under 2^22) to keep the GPU evenly loaded: then each pixel's sample range is cut
+ * has too few pixels (under 2^22) to keep the GPU evenly loaded and the pass
+ * has at least 16 samples: then each pixel's sample range is cut
  * into L contiguous slices (slice l = samples [l*per, (l+1)*per), per =
  * sample_count / L, the last slice takes the remainder) that run on different
  * lanes; each slice is summed in sample order, and the pass adds

@@ -1242,10 +1242,10 @@ uint32_t mcrt_lanes_per_pixel(uint32_t width, uint32_t height, uint32_t sample_c
 {
     // smallest power of two that brings pixels * slices to 2^22 work items (16 tile-sized fetches per resident
     // wavefront: measured, coarser items leave the GPU half empty while the last tiles finish), never more slices
-    // than samples
+    // than an eighth of the samples (items of fewer than 8 samples cost more in fetch/flush than they balance)
     const uint64_t pixels = (uint64_t)width * height;
     uint32_t l = 1;
-    while (l < 64u && pixels * l < (1ull << 22) && l * 2u <= sample_count) l *= 2u;
+    while (l < 64u && pixels * l < (1ull << 22) && l * 16u <= sample_count) l *= 2u;
     return l;
 }
 

@@ -106,10 +106,12 @@ def test_render_through_hbm_resident_octree(backend, pkg, oracle, scene_of, gold
         backend.upload_scene(flat, accel)
         assert not backend.octree_info().lds_resident
         backend.set_camera(cam)
+        backend.set_lanes_per_pixel(4)
         backend.clear(); backend.render(3, spp, 100, SEED)
         got = backend.read_accumulator()
         lanes = backend.lanes_per_pixel(spp)
-        assert lanes > 1 and spp % lanes != 0
+        backend.set_lanes_per_pixel(0)
+        assert lanes == 4 and spp % lanes != 0
         want, _ = oracle.render(sc, cam, 3, spp, 100, SEED, threads=8, portable_math=True, forward_sum=True, lanes_per_pixel=lanes)
         assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
     # per-sample radiance through the deep tree (k_trace_list, same walk)
@@ -205,10 +207,13 @@ def test_progressive_passes_and_sample_ranges(backend, pkg, scene_of, oracle):
     flat = _upload(backend, pkg, scene_of, "cornell")
     cam = oracle.camera(80, 56, 90.0, (0, 0, 5), (0, 0, 0))
     backend.set_camera(cam)
+    backend.set_lanes_per_pixel(8)
     backend.clear(); backend.render(0, 32, 100, SEED); backend.render(32, 32, 100, SEED)
     got = backend.read_accumulator()
     sc = oracle.scene(flat)
     lanes = backend.lanes_per_pixel(32)
+    backend.set_lanes_per_pixel(0)
+    assert lanes == 8
     want, _ = oracle.render(sc, cam, 0, 32, 100, SEED, threads=8, portable_math=True, forward_sum=True, lanes_per_pixel=lanes)
     want, _ = oracle.render(sc, cam, 32, 32, 100, SEED, threads=8, portable_math=True, forward_sum=True, sums=want, lanes_per_pixel=lanes)
     assert np.array_equal(got, want)

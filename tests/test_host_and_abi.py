@@ -273,4 +273,4 @@ def test_oracle_modes_agree(oracle, pkg, scene_of, golden):
 def test_lanes_per_pixel_rule(pkg):
     f = pkg.lanes_per_pixel
     assert f(2048, 2048, 256) == 1 and f(3840, 2160, 64) == 1                                   # big images: the reference's order
-    assert f(1024, 1024, 256) == 4 and f(512, 512, 64) == 16 and f(128, 128, 64) == 64 and f(128, 128, 5) == 4 and f(64, 64, 1) == 1
+    assert f(1024, 1024, 256) == 4 and f(512, 512, 64) == 8 and f(128, 128, 1024) == 64 and f(128, 128, 40) == 4 and f(64, 64, 7) == 1
