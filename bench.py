@@ -90,12 +90,19 @@ def main():
     pkg = mcrt_pkg.load()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # MCRT_BENCH_REHEARSE=1: every rank on GPU 0 with gloo, to walk the N>1 code path on a one-GPU box
+    # (the numbers mean nothing); the real run is one rank per GPU over RCCL.
+    rehearse = os.environ.get("MCRT_BENCH_REHEARSE") == "1"
+    device_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
 
     scene_name, width, height, spp = WORKLOADS[args.workload]
     if scene_name == "config4":
@@ -107,7 +114,7 @@ def main():
         flat = pkg.FlatScene.load(os.path.join(ROOT, "tests", "golden", f"scene_{scene_name}.npz"))
     cam = pkg.host_camera(width, height, 90.0, (0.0, 0.0, 5.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
 
-    be = pkg.Backend(local_rank)
+    be = pkg.Backend(device_index)
     stream = torch.cuda.current_stream()
     be.set_stream(stream.cuda_stream)
     be.upload_scene(flat)
@@ -122,7 +129,13 @@ def main():
     def step():
         be.clear()
         be.render(first_sample, spp, DEPTH, SEED)
-        sharding.reduce_accumulator(accum, dist, dst=0)          # RCCL over xGMI: one collective per pass
+        if rehearse and dist is not None:
+            host = accum.cpu()
+            sharding.reduce_accumulator(host, dist, dst=0)
+            if rank == 0:
+                accum.copy_(host)
+        else:
+            sharding.reduce_accumulator(accum, dist, dst=0)      # RCCL over xGMI: one collective per pass
         if rank == 0:
             be.resolve(pkg.TONEMAP_REINHARD, sharding.total_spp(world, spp), want_mean=False)
 
@@ -145,7 +158,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
