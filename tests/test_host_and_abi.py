@@ -274,3 +274,22 @@ def test_lanes_per_pixel_rule(pkg):
     f = pkg.lanes_per_pixel
     assert f(2048, 2048, 256) == 1 and f(3840, 2160, 64) == 1                                   # big images: the reference's order
     assert f(1024, 1024, 256) == 4 and f(512, 512, 64) == 8 and f(128, 128, 1024) == 64 and f(128, 128, 40) == 4 and f(64, 64, 7) == 1
+
+
+def test_flatten_under_sanitizers(tmp_path):
+    """The scene flattener (octree build + image layout, pure host C++) under ASan + UBSan: large soup, deep tree,
+    degenerate and invalid inputs (tests/native/flatten_sanitize.cpp)."""
+    import shutil
+    import subprocess
+
+    from conftest import ROOT
+
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "flatten_sanitize")
+    csrc = os.path.join(ROOT, "monte-carlo-ray-tracer_amd", "csrc")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    "-I", os.path.join(ROOT, "include"), "-I", csrc, os.path.join(ROOT, "tests", "native", "flatten_sanitize.cpp"),
+                    os.path.join(csrc, "mcrt_flatten.cpp"), "-o", exe], check=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all ok" in r.stdout, r.stdout + r.stderr
