@@ -46,10 +46,10 @@ def algorithmic_bytes_per_sample(cnt, spp):
     return (cnt["nodes"] * 32 + cnt["tris"] * 36 + cnt["spheres"] * 16 + cnt["gates"] * 24) / s + 24.0 / spp + 4.0 / spp
 
 
-def measured_traffic(workload):
-    """HBM bytes per k_render launch from the committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json);
-    PMC counters cannot be collected from inside this process, so the latest committed measurement of the
-    same workload is reported, or null."""
+def measured_counters(workload):
+    """The latest committed rocprofv3 PMC measurement of this workload (profiles/r*_pmc_traffic.json, written by
+    tools/summarize_profiles.py): HBM bytes per k_render launch and the VALU counters.  PMC counters cannot be
+    collected from inside this process, so the committed passes of the same command are reported, or null."""
     import glob
 
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
@@ -58,8 +58,8 @@ def measured_traffic(workload):
         except (OSError, ValueError):
             continue
         if entry:
-            return entry["traffic_bytes"]
-    return None
+            return entry
+    return {}
 
 
 def main():
@@ -183,6 +183,7 @@ def main():
     launch_bytes = bytes_per_sample * width * height * spp
     achieved = launch_bytes / (k_ms * 1e-3) / 1e9
 
+    pmc = measured_counters(args.workload) if args.accel == "auto" else {}
     out = {
         "metric": "Msamples/s (whole node) Cornell box; traversal HBM GB/s",
         "value": round(value, 3),
@@ -203,12 +204,15 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-            "traffic": measured_traffic(args.workload) if args.accel == "auto" else None,
+            "traffic": pmc.get("traffic_bytes"),
             "kernel": "k_render", "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_sample": round(bytes_per_sample, 2),
             "per_sample": {k: round(v / max(cnt["samples"], 1), 4) for k, v in cnt.items() if k != "samples"},
-            "note": ("scene image is read through scalar loads / LDS, not HBM: the kernel is VALU/latency bound, the HBM fraction is honest but small"
+            "valu_issue_busy": pmc.get("valu_issue_busy"), "active_lanes_per_valu_instruction": pmc.get("active_lanes_per_valu_instruction"),
+            "note": ("the algorithmic bytes (SURVEY.md 8d: one record per test) are served from SGPRs / LDS, not from HBM - `traffic` is what "
+                     "HBM saw per launch - so `frac` can exceed 1; the kernel is VALU-bound (`valu_issue_busy`, committed PMC pass)"
                      if (info.lds_resident or len(flat.triangles) <= 256) else
-                     "scene image (%.0f MB) is walked from HBM/L2 by divergent lanes: bound by cache-line requests and lane divergence, not by streaming bandwidth" % (info.blob_bytes / 1e6)),
+                     "scene image (%.0f MB) is walked from HBM/L2 by divergent lanes: bound by lane divergence and cache-line requests "
+                     "(`valu_issue_busy`, `active_lanes_per_valu_instruction`), not by streaming bandwidth" % (info.blob_bytes / 1e6)),
         },
     }
 
