@@ -233,7 +233,7 @@ def cpu_baseline(pkg, flat, scene_name, width, height):
     import pyoracle as po
 
     threads = min(16, os.cpu_count() or 1)
-    spp = 64
+    spp = max(8, min(256, int(1.3e8 / (width * height))))       # ~1.3e8 samples: 10-30 s of work on 16 cores
     if po.Ref.available():
         eng, kind = po.Ref(), "reference"
         cam = eng.camera(width, height, 90.0, (0.0, 0.0, 5.0), (0.0, 0.0, 0.0))

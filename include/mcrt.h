@@ -271,6 +271,13 @@ int mcrt_resolve(mcrt_ctx* ctx, int tonemap, double gamma, double exposure,
 /* Copy the raw accumulator sums to the host (width*height*3 doubles). */
 int mcrt_read_accumulator(mcrt_ctx* ctx, double* out_sums);
 
+/* Load accumulator sums from the host (width*height*3 doubles): the inverse of
+ * mcrt_read_accumulator, for resuming a render from a checkpoint.  The
+ * reference keeps PixelBuffer::data in host memory for the whole run and has no
+ * save/restore (source/core/pixelbuffer.h); a checkpoint is these doubles plus
+ * the number of samples already rendered and the seed. */
+int mcrt_write_accumulator(mcrt_ctx* ctx, const double* sums);
+
 /* Block until everything queued on the context's stream has finished. */
 int mcrt_synchronize(mcrt_ctx* ctx);
 

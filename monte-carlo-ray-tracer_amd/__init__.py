@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     "mcrt_create", "mcrt_destroy", "mcrt_last_error", "mcrt_set_stream", "mcrt_upload_scene", "mcrt_set_camera", "mcrt_set_accel",
     "mcrt_camera_rays", "mcrt_intersect", "mcrt_intersect_device", "mcrt_trace_samples", "mcrt_trace_rays", "mcrt_render_unlit", "mcrt_rng_seed",
     "mcrt_clear", "mcrt_bind_accumulator", "mcrt_accumulator", "mcrt_render", "mcrt_last_render_ms", "mcrt_resolve",
-    "mcrt_read_accumulator", "mcrt_synchronize", "mcrt_octree_info_get", "mcrt_octree_download", "mcrt_set_counting", "mcrt_counters",
+    "mcrt_read_accumulator", "mcrt_write_accumulator", "mcrt_synchronize", "mcrt_octree_info_get", "mcrt_octree_download", "mcrt_set_counting", "mcrt_counters",
     "mcrt_lanes_per_pixel", "mcrt_set_lanes_per_pixel",
     "mcrt_camera_look_at", "mcrt_scene_image_create", "mcrt_scene_image_destroy", "mcrt_scene_image_info", "mcrt_scene_image_octree",
 )
@@ -244,6 +244,11 @@ class Backend:
         mean = np.zeros((self.height, self.width, 3), np.float64) if want_mean else None
         self._ck(self.lib.mcrt_resolve(self.ctx, C.c_int(tonemap), C.c_double(gamma), C.c_double(exposure), C.c_uint64(spp_total), _ptr(bgra, C.c_uint8), _ptr(mean, C.c_double) if want_mean else None))
         return bgra, mean
+
+    def write_accumulator(self, sums):
+        sums = np.ascontiguousarray(sums, np.float64)
+        assert sums.size == self.width * self.height * 3
+        self._ck(self.lib.mcrt_write_accumulator(self.ctx, _ptr(sums, C.c_double)))
 
     def read_accumulator(self):
         out = np.zeros((self.height, self.width, 3), np.float64)

@@ -1302,6 +1302,17 @@ int mcrt_read_accumulator(mcrt_ctx* c, double* out)
     return MCRT_OK;
 }
 
+int mcrt_write_accumulator(mcrt_ctx* c, const double* sums)
+{
+    if (!c || !sums) return MCRT_ERR_INVALID;
+    if (!c->have_camera) return fail(c, MCRT_ERR_STATE, "no camera set (mcrt_set_camera)");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_accum, sums, c->accum_pixels * 24, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+
 int mcrt_synchronize(mcrt_ctx* c)
 {
     if (!c) return MCRT_ERR_INVALID;

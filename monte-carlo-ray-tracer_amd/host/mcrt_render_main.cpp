@@ -8,7 +8,11 @@
 // Usage: mcrt_render [--scene cornell|hexagon] [--width W] [--height H] [--spp N] [--pass P]
 //                    [--depth D] [--seed S] [--tonemap reinhard|exposure|none] [--gamma G]
 //                    [--exposure E] [--point-light] [--obj FILE x y z] [--unlit] [--device I]
-//                    [--out image.ppm] [--raw accum.f64]
+//                    [--out image.ppm] [--raw accum.f64] [--checkpoint FILE] [--resume FILE]
+//
+// --checkpoint FILE rewrites FILE after every pass (header: magic, width, height, samples done, seed; then the
+// W*H*3 accumulator doubles); --resume FILE continues such a render: samples [done, spp) are rendered on top of
+// the stored sums.  The reference has nothing comparable (its accumulators live and die with the process).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +23,42 @@
 #include "mcrt_scene.hpp"
 
 namespace {
+struct CheckpointHeader { char magic[8]; uint32_t width, height; uint64_t samples, seed; };
+
+bool WriteCheckpoint(const std::string& path, Scene& scene, Camera& camera, uint64_t samples, uint64_t seed)
+{
+    if (!scene.ReadBack(camera)) return false;
+    std::vector<double> sums(size_t(camera.pixels.numPixels()) * 3);
+    for (int y = 0; y < camera.pixels.height(); ++y)
+        for (int x = 0; x < camera.pixels.width(); ++x) {
+            ColorDbl c = camera.pixels.GetPixelColor(unsigned(x), unsigned(y));
+            double* p = &sums[(size_t(y) * size_t(camera.pixels.width()) + size_t(x)) * 3];
+            p[0] = c.r; p[1] = c.g; p[2] = c.b;
+        }
+    CheckpointHeader h = { { 'M', 'C', 'R', 'T', 'C', 'K', 'P', '1' }, uint32_t(camera.pixels.width()), uint32_t(camera.pixels.height()), samples, seed };
+    const std::string tmp = path + ".tmp";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    bool ok = std::fwrite(&h, sizeof h, 1, f) == 1 && std::fwrite(sums.data(), sizeof(double), sums.size(), f) == sums.size();
+    ok = (std::fclose(f) == 0) && ok;
+    return ok && std::rename(tmp.c_str(), path.c_str()) == 0;      // never leaves a half-written checkpoint behind
+}
+
+bool ReadCheckpoint(const std::string& path, unsigned width, unsigned height, uint64_t seed, std::vector<double>& sums, uint64_t& samples)
+{
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    CheckpointHeader h;
+    bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "MCRTCKP1", 8) == 0 && h.width == width && h.height == height && h.seed == seed;
+    if (ok) {
+        sums.resize(size_t(width) * height * 3);
+        ok = std::fread(sums.data(), sizeof(double), sums.size(), f) == sums.size();
+        samples = h.samples;
+    }
+    std::fclose(f);
+    return ok;
+}
+
 bool WritePPM(const std::string& path, const std::vector<uint8_t>& bgra, int w, int h)
 {
     FILE* f = std::fopen(path.c_str(), "wb");
@@ -39,7 +79,7 @@ bool WritePPM(const std::string& path, const std::vector<uint8_t>& bgra, int w, 
 
 int main(int argc, char** argv)
 {
-    std::string sceneName = "cornell", out = "render.ppm", raw, tonemapName = "reinhard", objPath;
+    std::string sceneName = "cornell", out = "render.ppm", raw, tonemapName = "reinhard", objPath, checkpoint, resume;
     unsigned width = 640, height = 480, spp = 64, pass = 64, depth = 100;   // main.cpp:33-41 defaults
     uint64_t seed = 0x5EED0001ull;
     double gamma = 2.2, exposure = 1.0;                                     // main.cpp:47-48
@@ -65,6 +105,8 @@ int main(int argc, char** argv)
         else if (a == "--device") device = std::atoi(next("--device"));
         else if (a == "--out") out = next("--out");
         else if (a == "--raw") raw = next("--raw");
+        else if (a == "--checkpoint") checkpoint = next("--checkpoint");
+        else if (a == "--resume") resume = next("--resume");
         else if (a == "--point-light") pointLight = true;
         else if (a == "--unlit") unlit = true;
         else if (a == "--obj") { objPath = next("--obj"); for (float& v : objPos) v = float(std::atof(next("--obj"))); }
@@ -115,11 +157,25 @@ int main(int argc, char** argv)
             image[p * 4 + 3] = 255;
         }
     } else {
-        for (unsigned done = 0; done < spp; done += pass) {
+        unsigned first = 0;
+        if (!resume.empty()) {
+            std::vector<double> sums;
+            uint64_t samples = 0;
+            if (!ReadCheckpoint(resume, width, height, seed, sums, samples) || samples > spp) {
+                std::fprintf(stderr, "cannot resume from %s (missing, or other image size / seed, or more samples than --spp)\n", resume.c_str());
+                return 1;
+            }
+            if (!scene->Restore(camera, sums, samples)) return 1;
+            first = unsigned(samples);
+            std::printf("Resumed at %u of %u spp\r\n", first, spp);
+        }
+        for (unsigned done = first; done < spp; done += pass) {
             const unsigned n = std::min(pass, spp - done);
             if (!scene->Render(camera, done, n, depth, seed)) return 1;
             if (!scene->Resolve(camera, tonemap, gamma, exposure, image)) return 1;      // what the window would show after this pass
+            if (!checkpoint.empty() && !WriteCheckpoint(checkpoint, *scene, camera, done + n, seed)) { std::fprintf(stderr, "cannot write %s\n", checkpoint.c_str()); return 1; }
         }
+        if (first >= spp && !scene->Resolve(camera, tonemap, gamma, exposure, image)) return 1;
     }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("Render finished at %.3f s: %ux%u, %u spp, %.1f Msamples/s\r\n", secs, width, height, spp,

@@ -329,6 +329,19 @@ bool Scene::ReadBack(Camera& camera)
     return mcrt_read_accumulator(ctx, camera.pixels.data.data()) == MCRT_OK || Fail("read_accumulator");
 }
 
+bool Scene::Restore(Camera& camera, const std::vector<double>& sums, uint64_t samplesDone)
+{
+    if (!prepared) return Fail("Restore before PrepareForRayTracing");
+    if (sums.size() != size_t(camera.pixels.numPixels()) * 3) return Fail("Restore: wrong accumulator size");
+    if (boundCamera != &camera) {
+        if (mcrt_set_camera(ctx, &camera.view) != MCRT_OK) return Fail("set_camera");
+        boundCamera = &camera;
+    }
+    if (mcrt_write_accumulator(ctx, sums.data()) != MCRT_OK) return Fail("write_accumulator");
+    camera.pixels.rays = samplesDone;
+    return true;
+}
+
 bool Scene::Resolve(Camera& camera, int tonemap, double gamma, double exposure, std::vector<uint8_t>& bgra8)
 {
     if (boundCamera != &camera || camera.pixels.rays == 0) return Fail("Resolve: nothing rendered with this camera");

@@ -224,6 +224,8 @@ public:
     // Batch entry points (what replaces TracePixels, source/main.cpp:169-184).
     bool Render(Camera& camera, uint32_t sampleBegin, uint32_t sampleCount, unsigned int traceDepth, uint64_t seed);
     bool ReadBack(Camera& camera);                                   // device accumulators -> camera.pixels
+    // camera.pixels (sums of `samplesDone` samples per pixel, e.g. from a checkpoint) -> device accumulators
+    bool Restore(Camera& camera, const std::vector<double>& sums, uint64_t samplesDone);
     bool Resolve(Camera& camera, int tonemap, double gamma, double exposure, std::vector<uint8_t>& bgra8);
     bool Clear(Camera& camera);
 

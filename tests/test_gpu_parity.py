@@ -347,3 +347,28 @@ def test_headless_driver_matches_library(backend, pkg, oracle, scene_of, tmp_pat
     assert data.startswith(head)
     rgb = np.frombuffer(data[len(head):], np.uint8).reshape(72, 96, 3)
     assert np.array_equal(rgb, bgra[..., 2::-1])
+
+
+def test_checkpoint_and_resume(backend, pkg, scene_of, tmp_path):
+    """Accumulator checkpoint / resume: a render continued from a checkpoint in a new process
+    equals the uninterrupted one bit for bit; mcrt_write_accumulator is the inverse of mcrt_read_accumulator."""
+    import os
+    import subprocess
+
+    from conftest import ROOT
+
+    exe = os.path.join(ROOT, "monte-carlo-ray-tracer_amd", "mcrt_render")
+    ck, r1, r2 = tmp_path / "ck.bin", tmp_path / "a.f64", tmp_path / "b.f64"
+    common = [exe, "--width", "64", "--height", "40", "--pass", "4", "--out", str(tmp_path / "o.ppm")]
+    subprocess.run(common + ["--spp", "8", "--checkpoint", str(ck)], check=True, timeout=120)
+    subprocess.run(common + ["--spp", "16", "--resume", str(ck), "--raw", str(r1)], check=True, timeout=120)
+    subprocess.run(common + ["--spp", "16", "--raw", str(r2)], check=True, timeout=120)
+    a, b = np.fromfile(r1, np.float64), np.fromfile(r2, np.float64)
+    assert a.size == 64 * 40 * 3 and np.array_equal(a, b)
+    # a checkpoint of another image size is refused
+    bad = subprocess.run([exe, "--width", "32", "--height", "40", "--spp", "16", "--resume", str(ck), "--out", str(tmp_path / "p.ppm")], timeout=120)
+    assert bad.returncode != 0
+    _upload(backend, pkg, scene_of, "cornell")
+    backend.set_camera(pkg.host_camera(64, 40, 90.0, (0, 0, 5), (0, 0, 0)))
+    backend.write_accumulator(b)
+    assert np.array_equal(backend.read_accumulator().reshape(-1), b)
