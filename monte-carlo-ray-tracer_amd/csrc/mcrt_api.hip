@@ -76,16 +76,18 @@ template <bool kBigLds, int kAccel> struct SceneMem {
         big = big_ptr<kBigLds>(v, smem);
     }
 };
-// flat scan: object records through scalar loads, triangle records from the LDS copy of BIG
+// flat scan: object records through scalar loads, triangle records from an LDS copy (the view these kernels get has
+// off_tri == 0: flat_view() on the host), nothing else of the images is staged
 template <bool kBigLds> struct SceneMem<kBigLds, MCRT_ACCEL_FLAT> {
     typedef CstPtr PS;
     typedef LdsPtr PB;
     static __device__ __forceinline__ void open(const SceneView& v, uint32_t* smem, PS& sm, PB& big)
     {
-        static_assert(kBigLds, "the flat scan needs the BIG image in LDS");
-        stage_scene<true>(v, smem);
+        const uint32_t words = v.ntri * TRI_STRIDE;
+        for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) smem[i] = v.big_img[v.tri_src + i];
+        __syncthreads();
         sm = (CstPtr)v.small_img;
-        big = big_ptr<true>(v, smem);
+        big = (LdsPtr)smem;
     }
 };
 template <bool kBigLds> struct SceneMem<kBigLds, MCRT_ACCEL_SCAN> {
@@ -731,15 +733,27 @@ int fail(mcrt_ctx* c, int code, const std::string& msg)
 
 int bind_device(mcrt_ctx* c) { HIP_TRY(c, hipSetDevice(c->device)); return MCRT_OK; }
 
+size_t flat_lds_bytes(const mcrt_ctx* c);
 size_t lds_for(const mcrt_ctx* c)
 {
     if (c->accel == MCRT_ACCEL_SCAN) return 0;
-    if (c->accel == MCRT_ACCEL_FLAT) return c->lds_bytes + 16u + (kBlock / 64) * FLAT_AREA_WORDS * 4u;
+    if (c->accel == MCRT_ACCEL_FLAT) return flat_lds_bytes(c);
     return c->lds_bytes + ((c->accel == MCRT_ACCEL_OCTREE && !c->big_in_lds) ? kWalkLdsWords * 4u : 0u);
 }
 
-// the flat scan keeps BIG in LDS and packs (object, element) into 32 bits
-bool flat_ok(const mcrt_ctx* c) { return c->big_in_lds && c->view.has_pairs && c->view.ntri < (1u << FLAT_ELEM_BITS) && c->view.nobj <= 64u; }
+// the flat scan keeps the triangle records and its per-wavefront work areas in LDS and packs (object, element) into 32 bits
+size_t flat_lds_bytes(const mcrt_ctx* c) { return (size_t)c->view.ntri * TRI_STRIDE * 4u + 16u + (kBlock / 64) * FLAT_AREA_WORDS * 4u; }
+bool flat_ok(const mcrt_ctx* c)
+{
+    return c->view.has_pairs && c->view.ntri < (1u << FLAT_ELEM_BITS) && c->view.nobj <= 64u && flat_lds_bytes(c) <= 40u * 1024u;   // 4 blocks per CU
+}
+// what the kernels of the current accel mode get: the flat scan addresses triangles in its LDS copy
+SceneView view_for(const mcrt_ctx* c)
+{
+    SceneView v = c->view;
+    if (c->accel == MCRT_ACCEL_FLAT) v.off_tri = 0;
+    return v;
+}
 
 void resolve_accel(mcrt_ctx* c)
 {
@@ -796,7 +810,7 @@ int launch_intersect_t(mcrt_ctx* c, uint64_t n, const float* o, const float* d, 
     if (rc) return rc;
     uint32_t blocks = (uint32_t)std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)grid_for(c) * 4);
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kBlock), lds_for(c), c->stream, c->view, n, o, d, obj, elem, t, c->d_counters);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kBlock), lds_for(c), c->stream, view_for(c), n, o, d, obj, elem, t, c->d_counters);
     HIP_TRY(c, hipGetLastError());
     return MCRT_OK;
 }
@@ -805,7 +819,7 @@ template <bool kBigLds, int kAccel> int launch_unlit_t(mcrt_ctx* c, double* out)
     auto kern = k_unlit<kBigLds, kAccel>;
     int rc = set_lds_limit(c, kern, lds_for(c));
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid_for(c)), dim3(kBlock), lds_for(c), c->stream, c->view, c->cam, out);
+    hipLaunchKernelGGL(kern, dim3(grid_for(c)), dim3(kBlock), lds_for(c), c->stream, view_for(c), c->cam, out);
     HIP_TRY(c, hipGetLastError());
     return MCRT_OK;
 }
@@ -1088,7 +1102,7 @@ int mcrt_trace_samples(mcrt_ctx* c, uint64_t n, const uint32_t* pixels, const ui
     HIP_TRY(c, hipMemcpyAsync(ds.p, samples, n * 4, hipMemcpyHostToDevice, c->stream));
     if (c->counting) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
     ListArgs a;
-    a.view = c->view; a.cam = c->cam; a.pixels = dp.p; a.samples = ds.p; a.out = dout.p; a.counters = c->d_counters; a.pend = c->d_pend;
+    a.view = view_for(c); a.cam = c->cam; a.pixels = dp.p; a.samples = ds.p; a.out = dout.p; a.counters = c->d_counters; a.pend = c->d_pend;
     a.n = n; a.max_depth = max_depth; a.seed = seed;
     a.ray_o = nullptr; a.ray_d = nullptr; a.ray_state = nullptr; a.ray_importance = nullptr;
     a.refill = walk_refill(c);
@@ -1123,7 +1137,7 @@ int mcrt_trace_rays(mcrt_ctx* c, uint64_t n, const float* origins, const float* 
     }
     if (c->counting) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
     ListArgs a;
-    a.view = c->view; a.cam = c->cam; a.pixels = nullptr; a.samples = nullptr; a.out = dout.p; a.counters = c->d_counters; a.pend = c->d_pend;
+    a.view = view_for(c); a.cam = c->cam; a.pixels = nullptr; a.samples = nullptr; a.out = dout.p; a.counters = c->d_counters; a.pend = c->d_pend;
     a.n = n; a.max_depth = max_depth; a.seed = 0;
     a.ray_o = dor.p; a.ray_d = ddi.p; a.ray_state = dst.p; a.ray_importance = dimp.p;
     a.refill = walk_refill(c);
@@ -1194,7 +1208,7 @@ int mcrt_render(mcrt_ctx* c, uint32_t sample_begin, uint32_t sample_count, uint3
     HIP_TRY(c, hipMemsetAsync(c->d_tile, 0, 2 * sizeof(uint32_t), c->stream));
     if (c->counting) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
     RenderArgs a;
-    a.view = c->view; a.cam = c->cam; a.accum = c->d_accum; a.tile_counter = c->d_tile; a.counters = c->d_counters; a.pend = c->d_pend;
+    a.view = view_for(c); a.cam = c->cam; a.accum = c->d_accum; a.tile_counter = c->d_tile; a.counters = c->d_counters; a.pend = c->d_pend;
     a.s_begin = sample_begin; a.s_count = sample_count; a.max_depth = max_depth;
     a.refill = walk_refill(c);
     a.slices = c->lanes_override ? std::min<uint32_t>(c->lanes_override, sample_count) : mcrt_lanes_per_pixel(c->cam.width, c->cam.height, sample_count);

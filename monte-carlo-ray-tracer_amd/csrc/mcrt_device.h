@@ -839,8 +839,8 @@ template <int kAccel, class PS, class PB, bool kCount> struct Caster {
 template <bool kCount> struct Caster<MCRT_ACCEL_FLAT, CstPtr, LdsPtr, kCount> {
     static MCRT_DEV Hit run(CstPtr sm, LdsPtr big, const SceneView& v, V3 o, V3 d, Counters& cn)
     {
-        // the per-wavefront work area follows the staged BIG image in LDS
-        LdsRw area = (LdsRw)(big + ((v.big_words + 3u) & ~3u)) + (threadIdx.x >> 6) * FLAT_AREA_WORDS;
+        // the per-wavefront work area follows the staged triangle records in LDS
+        LdsRw area = (LdsRw)(big + ((v.ntri * TRI_STRIDE + 3u) & ~3u)) + (threadIdx.x >> 6) * FLAT_AREA_WORDS;
         return cast_flat<kCount>(sm, big, area, v, o, d, cn);
     }
 };

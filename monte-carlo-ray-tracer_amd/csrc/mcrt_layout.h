@@ -91,6 +91,8 @@ struct SceneView {
     uint32_t off_obj, off_lights, off_bg;            // into SMALL
     uint32_t off_node, off_leaf, off_tri, off_pair;  // into BIG (all multiples of 4 words)
     uint32_t has_pairs;          // triangle-pair records present (scan path usable)
+    uint32_t tri_src;            // word offset of the triangle records in the global BIG image (== off_tri except in the
+                                 // view handed to the flat-scan kernels, whose off_tri addresses their LDS copy)
 };
 
 } // namespace mcrt
