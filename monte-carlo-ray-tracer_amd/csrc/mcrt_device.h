@@ -478,25 +478,34 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
         if (mask) {
             const uint32_t base = cw & 0x00FFFFFFu;
             // All eight octant slots are fetched unconditionally (an absent octant re-reads the first child: same
-            // cache line) so the sixteen 16-byte loads are in flight together; far octants are pushed first so
-            // the nearest is popped first.
+            // cache line); far octants are pushed first so the nearest is popped first.
+            // two batches of four slots: all eight loads of a batch are issued before the first test
 #pragma unroll
-            for (int k = 7; k >= 0; --k) {
-                const uint32_t oct = (uint32_t)k ^ flip;
-                const bool exists = (mask >> oct) & 1u;
-                const uint32_t child = exists ? base + __popc(mask & ((1u << oct) - 1u)) : base;
-                const U4 lo = ld4(nodes, child * NODE_STRIDE), hi = ld4(nodes, child * NODE_STRIDE + 4);
-                float t0 = 0.0f, t1 = best.t;
-                float p = (__uint_as_float(lo.x) - o.x) * ix;
-                float q = (__uint_as_float(lo.w) - o.x) * ix;
-                t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
-                p = (__uint_as_float(lo.y) - o.y) * iy;
-                q = (__uint_as_float(hi.x) - o.y) * iy;
-                t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
-                p = (__uint_as_float(lo.z) - o.z) * iz;
-                q = (__uint_as_float(hi.y) - o.z) * iz;
-                t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
-                if (exists && t0 <= t1) { st.put(sp, t0, hi.z, hi.w); ++sp; }
+            for (int batch = 1; batch >= 0; --batch) {
+                U4 lo[4], hi[4];
+                bool exists[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t oct = (uint32_t)(batch * 4 + 3 - j) ^ flip;
+                    exists[j] = (mask >> oct) & 1u;
+                    const uint32_t child = exists[j] ? base + __popc(mask & ((1u << oct) - 1u)) : base;
+                    lo[j] = ld4(nodes, child * NODE_STRIDE);
+                    hi[j] = ld4(nodes, child * NODE_STRIDE + 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t0 = 0.0f, t1 = best.t;
+                    float p = (__uint_as_float(lo[j].x) - o.x) * ix;
+                    float q = (__uint_as_float(lo[j].w) - o.x) * ix;
+                    t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
+                    p = (__uint_as_float(lo[j].y) - o.y) * iy;
+                    q = (__uint_as_float(hi[j].x) - o.y) * iy;
+                    t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
+                    p = (__uint_as_float(lo[j].z) - o.z) * iz;
+                    q = (__uint_as_float(hi[j].y) - o.z) * iz;
+                    t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
+                    if (exists[j] && t0 <= t1) { st.put(sp, t0, hi[j].z, hi[j].w); ++sp; }
+                }
             }
         }
     }
