@@ -708,9 +708,13 @@ struct mcrt_ctx {
     size_t pend_words = 0;
     uint32_t grid_blocks = 0;
     uint32_t lanes_override = 0;                // mcrt_set_lanes_per_pixel (0: automatic)
+    uint8_t* d_resolve_img = nullptr;           // mcrt_resolve staging, grown on demand
+    double* d_resolve_mean = nullptr;
+    size_t resolve_img_pixels = 0, resolve_mean_pixels = 0;
     double* d_partial = nullptr;                // slice sums of the current pass, [slices][pixels][3]
     size_t partial_bytes = 0;
     int chunk_override = 0;                     // MCRT_LEAF_CHUNK (tuning knob)
+    uint32_t wave_slices = 64;                  // MCRT_WAVE_SLICES (tuning knob): slices of a pixel that share a wavefront, at most
     int refill_override = -1;                   // MCRT_REFILL (tuning knob): see RenderArgs::refill
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -907,6 +911,7 @@ int mcrt_create(int device_id, mcrt_ctx** out_ctx)
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("MCRT_REFILL")) { int r = atoi(e); if (r >= 0 && r <= 64) c->refill_override = r; }
+    if (const char* e = getenv("MCRT_WAVE_SLICES")) { int r = atoi(e); if (r >= 1 && r <= 64) c->wave_slices = (uint32_t)r; }
     if (const char* e = getenv("MCRT_LEAF_CHUNK")) { int r = atoi(e); if (r > 0 && r < (1 << 20)) c->chunk_override = r; }
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     c->stream = c->own_stream;
@@ -930,6 +935,8 @@ int mcrt_destroy(mcrt_ctx* c)
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_tile) (void)hipFree(c->d_tile);
     if (c->d_partial) (void)hipFree(c->d_partial);
+    if (c->d_resolve_img) (void)hipFree(c->d_resolve_img);
+    if (c->d_resolve_mean) (void)hipFree(c->d_resolve_mean);
     if (c->d_pend) (void)hipFree(c->d_pend);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1216,8 +1223,7 @@ int mcrt_render(mcrt_ctx* c, uint32_t sample_begin, uint32_t sample_count, uint3
         // the slices of a pixel share a wavefront (4 slices: 4x4 pixels x 4 slices): a smaller pixel footprint per
         // wavefront keeps its primary rays, first hits and shading branches together (+6..8 % measured);
         // MCRT_WAVE_SLICES overrides (tuning knob)
-        uint32_t ws = 64;
-        if (const char* e = getenv("MCRT_WAVE_SLICES")) ws = (uint32_t)atoi(e);
+        const uint32_t ws = c->wave_slices;
         uint32_t lg = 0;
         while ((2u << lg) <= ws && (2u << lg) <= a.slices && a.slices % (2u << lg) == 0 && lg < 6) ++lg;
         a.wave_slices_log2 = lg;
@@ -1291,16 +1297,25 @@ int mcrt_resolve(mcrt_ctx* c, int tonemap, double gamma, double exposure, uint64
     int rc = bind_device(c);
     if (rc) return rc;
     const uint64_t npix = c->accum_pixels;
-    DevBuf<uint8_t> dimg;
-    DevBuf<double> dmean;
-    if (out_bgra8) HIP_TRY(c, hipMalloc(&dimg.p, npix * 4));
-    if (out_mean) HIP_TRY(c, hipMalloc(&dmean.p, npix * 24));
+    // the staging images live with the context (a progressive driver resolves after every pass)
+    if (out_bgra8 && c->resolve_img_pixels < npix) {
+        if (c->d_resolve_img) { (void)hipFree(c->d_resolve_img); c->d_resolve_img = nullptr; c->resolve_img_pixels = 0; }
+        HIP_TRY(c, hipMalloc(&c->d_resolve_img, npix * 4));
+        c->resolve_img_pixels = npix;
+    }
+    if (out_mean && c->resolve_mean_pixels < npix) {
+        if (c->d_resolve_mean) { (void)hipFree(c->d_resolve_mean); c->d_resolve_mean = nullptr; c->resolve_mean_pixels = 0; }
+        HIP_TRY(c, hipMalloc(&c->d_resolve_mean, npix * 24));
+        c->resolve_mean_pixels = npix;
+    }
+    uint8_t* dimg = out_bgra8 ? c->d_resolve_img : nullptr;
+    double* dmean = out_mean ? c->d_resolve_mean : nullptr;
     uint32_t blocks = (uint32_t)std::min<uint64_t>((npix + kBlock - 1) / kBlock, 65535);
     hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(kBlock), 0, c->stream, (const double*)c->d_accum, npix, (double)spp_total, tonemap,
-                       1.0 / gamma, exposure, dimg.p, dmean.p);
+                       1.0 / gamma, exposure, dimg, dmean);
     HIP_TRY(c, hipGetLastError());
-    if (out_bgra8) HIP_TRY(c, hipMemcpyAsync(out_bgra8, dimg.p, npix * 4, hipMemcpyDeviceToHost, c->stream));
-    if (out_mean) HIP_TRY(c, hipMemcpyAsync(out_mean, dmean.p, npix * 24, hipMemcpyDeviceToHost, c->stream));
+    if (out_bgra8) HIP_TRY(c, hipMemcpyAsync(out_bgra8, dimg, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    if (out_mean) HIP_TRY(c, hipMemcpyAsync(out_mean, dmean, npix * 24, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MCRT_OK;
 }
