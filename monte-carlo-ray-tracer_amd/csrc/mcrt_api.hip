@@ -2,12 +2,14 @@
 //
 // Kernel family (all hand-written for gfx950, 64-wide wavefronts):
 //   k_render        the hot loop of source/main.cpp:100-184 + Scene::TraceRay
-//                   (source/scene.cpp:94-234): persistent workgroups pull 8x8
-//                   pixel tiles from an atomic counter; one lane owns one pixel
-//                   and walks its samples; every loop iteration is exactly one
-//                   nearest-hit query (camera/bounce ray or shadow ray), so the
-//                   wave stays converged on the expensive part while lanes sit in
-//                   different path states.
+//                   (source/scene.cpp:94-234): persistent workgroups pull work
+//                   items (sample slice, pixel) from an atomic counter; a lane
+//                   renders the samples of its item in order; every loop
+//                   iteration is exactly one nearest-hit query (camera/bounce
+//                   ray or shadow ray), so the wave stays converged on the
+//                   expensive part while lanes sit in different path states.
+//   k_combine       adds the slice sums of a pass to the accumulators in slice
+//                   order (images too small to fill the GPU with one lane per pixel).
 //   k_trace_list    the same per-sample code on an explicit (pixel, sample) list
 //                   (parity entry point mcrt_trace_samples).
 //   k_intersect     Scene::IntersectRay (source/scene.cpp:62-80) on a ray batch.
@@ -20,6 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -27,7 +30,6 @@
 
 #include "mcrt.h"
 #include "mcrt_device.h"
-#include <cstdlib>
 #include "mcrt_flatten.h"
 
 using namespace mcrt;

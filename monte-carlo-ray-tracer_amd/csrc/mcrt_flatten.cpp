@@ -5,7 +5,7 @@
 // InsertIfOverlaps (source/accelerationstructures/octree.h:50-92,168-223) are
 // rebuilt as a per-PRIMITIVE octree (the reference's is per object, never
 // queried and non-functional) that is then flattened
-// breadth-first into the SoA arrays of mcrt_layout.h.
+// breadth-first into the node / leaf records of mcrt_layout.h.
 //
 // What is kept from the reference structure: 8-way axis-aligned subdivision
 // at the cell centre, a `maxCount` leaf threshold (octree.h:31), the root box
@@ -14,8 +14,9 @@
 // queries equal the brute force of source/scene.cpp:62-80 exactly:
 //   - members are single triangles / spheres with their TRUE bounds (the
 //     reference boxes spheres at half size, source/objects/sphere.h:71-74);
-//   - a primitive larger than a child cell stays in the interior node's own
-//     list instead of being copied into every child it touches;
+//   - a primitive much larger than a child cell stays in the interior node's
+//     own list; the others go into every child whose cell the triangle itself
+//     (not just its box) overlaps;
 //   - every node stores the padded union of (member box  intersect  cell), so
 //     a float slab test on it can never cull a node holding the nearest hit.
 #include "mcrt_flatten.h"
