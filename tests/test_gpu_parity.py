@@ -372,3 +372,25 @@ def test_checkpoint_and_resume(backend, pkg, scene_of, tmp_path):
     backend.set_camera(pkg.host_camera(64, 40, 90.0, (0, 0, 5), (0, 0, 0)))
     backend.write_accumulator(b)
     assert np.array_equal(backend.read_accumulator().reshape(-1), b)
+
+
+def test_plain_c_example(tmp_path):
+    """examples/minimal.c: the ABI used from C99 (hand-built scene -> render -> resolve -> PPM)."""
+    import os
+    import shutil
+    import subprocess
+
+    from conftest import ROOT
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    lib = os.path.join(ROOT, "monte-carlo-ray-tracer_amd")
+    exe = str(tmp_path / "minimal")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "minimal.c"),
+                    "-L", lib, "-lmcrt_hip", f"-Wl,-rpath,{lib}", "-lm", "-o", exe], check=True, timeout=120)
+    r = subprocess.run([exe, str(tmp_path / "m.ppm")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lit = int(r.stdout.split(",")[1].split()[0])
+    assert 12000 < lit < 30000, r.stdout          # floor, back wall and light cover about a third of the frame; the rest is background
+    data = open(tmp_path / "m.ppm", "rb").read()
+    assert data.startswith(b"P6\n256 192\n255\n") and len(data) == 15 + 256 * 192 * 3
