@@ -631,6 +631,23 @@ MCRT_DEV bool gate_hit_fast(CstPtr rec, V3 o, V3 d, V3 inv, bool exact_only)
     return tmax >= tmin;
 }
 
+// Exact tails of a triangle pair.  A ray is a candidate for at most one triangle of a pair almost always (the two
+// halves of a quad), so the candidate's intermediates are selected first and ONE exact tail - the IEEE division and
+// the reference's comparisons - serves both; a lane that is a candidate for both (it grazes the shared edge) takes
+// the second tail afterwards.  Order and strictness are those of the sequential loop: triangle k, then k + 1.
+MCRT_DEV void pair_exact(F2 a, F2 x, F2 y, F2 z, uint32_t obj, uint32_t k, Hit& best)
+{
+    const bool cx = tri_maybe(a.x, x.x, y.x, z.x, best.t), cy = tri_maybe(a.y, x.y, y.y, z.y, best.t);
+    if (cx || cy) {
+        float t;
+        const bool second = !cx;
+        if (tri_exact_tail(second ? a.y : a.x, second ? x.y : x.x, second ? y.y : y.x, second ? z.y : z.x, best.t, t)) {
+            best.obj = obj; best.elem = k + (second ? 1u : 0u); best.t = t;
+        }
+        if (cx && cy && tri_maybe(a.y, x.y, y.y, z.y, best.t) && tri_exact_tail(a.y, x.y, y.y, z.y, best.t, t)) { best.obj = obj; best.elem = k + 1u; best.t = t; }
+    }
+}
+
 template <bool kCount>
 MCRT_DEV Hit cast_scan(CstPtr sm, CstPtr big, const SceneView& v, V3 o, V3 d, Counters& cn)
 {
@@ -680,10 +697,8 @@ MCRT_DEV Hit cast_scan(CstPtr sm, CstPtr big, const SceneView& v, V3 o, V3 d, Co
                     const F2 qx = sy * e1z - e1y * sz, qy = sz * e1x - e1z * sx, qz = sx * e1y - e1x * sy;          // cross(s, edge1)
                     const F2 y = dot2(F2(d.x), F2(d.y), F2(d.z), qx, qy, qz);
                     const F2 z = dot2(e2x, e2y, e2z, qx, qy, qz);
-                    float t;
                     if (kCount) cn.tris += (k + 1 < count) ? 2u : 1u;
-                    if (tri_maybe(a.x, x.x, y.x, z.x, best.t) && tri_exact_tail(a.x, x.x, y.x, z.x, best.t, t)) { best.obj = i; best.elem = k; best.t = t; }
-                    if (tri_maybe(a.y, x.y, y.y, z.y, best.t) && tri_exact_tail(a.y, x.y, y.y, z.y, best.t, t)) { best.obj = i; best.elem = k + 1; best.t = t; }
+                    pair_exact(a, x, y, z, i, k, best);
                 }
             }
         }
@@ -787,10 +802,8 @@ MCRT_DEV Hit cast_flat(CstPtr sm, LdsPtr big, LdsRw area, const SceneView& v, V3
                     const F2 qx = sy * e1z - e1y * sz, qy = sz * e1x - e1z * sx, qz = sx * e1y - e1x * sy;          // cross(s, edge1)
                     const F2 y = dot2(F2(d.x), F2(d.y), F2(d.z), qx, qy, qz);
                     const F2 z = dot2(e2x, e2y, e2z, qx, qy, qz);
-                    float t;
                     if (kCount) cn.tris += (k + 1 < count) ? 2u : 1u;
-                    if (tri_maybe(a.x, x.x, y.x, z.x, best.t) && tri_exact_tail(a.x, x.x, y.x, z.x, best.t, t)) { best.obj = i; best.elem = k; best.t = t; }
-                    if (tri_maybe(a.y, x.y, y.y, z.y, best.t) && tri_exact_tail(a.y, x.y, y.y, z.y, best.t, t)) { best.obj = i; best.elem = k + 1; best.t = t; }
+                    pair_exact(a, x, y, z, i, k, best);
                 }
             }
             continue;
