@@ -593,7 +593,8 @@ MCRT_DEV bool tri_maybe(float a, float x, float y, float z, float best_t)
 
 // AABB::IntersectsRay (source/core/aabb.h:49-96): decided on reciprocal-multiply slabs when the
 // outcome is clear, on the exact quotients otherwise.  `inv` = approximate 1/d per axis; `exact_only`
-// is set for rays with a denormal-range direction component (their approximate slabs overflow).
+// is set for rays with a zero or denormal-range direction component (an axis the reference skips, or approximate
+// slabs that overflow).
 MCRT_DEV bool gate_hit_fast(CstPtr rec, V3 o, V3 d, V3 inv, bool exact_only)
 {
     const U8 b = *(const __attribute__((address_space(4))) U8*)(rec + OBJ_AABB_MIN);
@@ -601,15 +602,14 @@ MCRT_DEV bool gate_hit_fast(CstPtr rec, V3 o, V3 d, V3 inv, bool exact_only)
     const float mx[3] = { __uint_as_float(b.s3), __uint_as_float(b.s4), __uint_as_float(b.s5) };
     const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z }, ii[3] = { inv.x, inv.y, inv.z };
     float tmin = -kFltMax, tmax = kFltMax;
+    // every direction component is a normal, non-zero number here (exact_only covers the rest), so the products are
+    // finite or +-inf, never NaN, and plain min / max instructions do
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float t1 = (mn[a] - oo[a]) * ii[a];
         const float t2 = (mx[a] - oo[a]) * ii[a];
-        const float lo = (t2 < t1) ? t2 : t1;
-        const float hi = (t1 < t2) ? t2 : t1;
-        const bool use = dd[a] != 0.0f;
-        tmin = (use && tmin < lo) ? lo : tmin;
-        tmax = (use && hi < tmax) ? hi : tmax;
+        tmin = fmaxf(tmin, fminf(t1, t2));
+        tmax = fminf(tmax, fmaxf(t1, t2));
     }
     const float diff = tmax - tmin;
     const float tol = 4.0e-6f * (fabsf(tmax) + fabsf(tmin)) + 1.0e-30f;
@@ -655,7 +655,7 @@ MCRT_DEV Hit cast_scan(CstPtr sm, CstPtr big, const SceneView& v, V3 o, V3 d, Co
     if (kCount) cn.rays++;
     const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     const float tiny = 1.0e-20f;
-    const bool exact_only = (d.x != 0.0f && fabsf(d.x) < tiny) || (d.y != 0.0f && fabsf(d.y) < tiny) || (d.z != 0.0f && fabsf(d.z) < tiny);
+    const bool exact_only = fabsf(d.x) < tiny || fabsf(d.y) < tiny || fabsf(d.z) < tiny;
     CstPtr rec = sm + v.off_obj;
     for (uint32_t i = 0; i < v.nobj; ++i, rec += OBJ_STRIDE) {
         const U8 head = *(const __attribute__((address_space(4))) U8*)rec;   // kind, first_tri, tri_count, first_prim, radius, pos
@@ -754,7 +754,7 @@ MCRT_DEV Hit cast_flat(CstPtr sm, LdsPtr big, LdsRw area, const SceneView& v, V3
     Hit best; best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax;     // spheres and widely needed meshes: tested by the ray's own lane
     const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     const float tiny = 1.0e-20f;
-    const bool exact_only = (d.x != 0.0f && fabsf(d.x) < tiny) || (d.y != 0.0f && fabsf(d.y) < tiny) || (d.z != 0.0f && fabsf(d.z) < tiny);
+    const bool exact_only = fabsf(d.x) < tiny || fabsf(d.y) < tiny || fabsf(d.z) < tiny;
     CstPtr rec = sm + v.off_obj;
     for (uint32_t i = 0; i < v.nobj; ++i, rec += OBJ_STRIDE) {
         const U8 head = *(const __attribute__((address_space(4))) U8*)rec;   // kind, first_tri, tri_count, first_prim, radius, pos
