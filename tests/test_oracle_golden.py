@@ -126,3 +126,26 @@ def test_oracle_against_live_reference(oracle, ref, scene_of):
     a = ref.trace_samples(ref.scene(flat), cam_r, px, sm, 99, 100)
     b = oracle.trace_samples(oracle.scene(flat), cam_o, px, sm, 99, 100)
     assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def test_oracle_slice_order_is_what_the_header_says(oracle, scene_of):
+    """orc_render(lanes_per_pixel=L) - the order the GPU parity tests compare against - equals the per-sample radiances
+    of orc_trace_samples summed as include/mcrt.h (mcrt_lanes_per_pixel) describes: contiguous slices, each summed in
+    sample order, the last one taking the remainder, slice sums added in slice order, then added to the accumulator."""
+    sc = oracle.scene(scene_of("cornell"))
+    cam = oracle.camera(12, 8, 90.0, (0, 0, 5), (0, 0, 0))
+    seed, spp, begin = 0x5EED0001, 11, 3
+    start = np.full((8, 12, 3), 0.25)
+    for lanes in (1, 2, 4, 11):
+        got, _ = oracle.render(sc, cam, begin, spp, 100, seed, threads=2, lanes_per_pixel=lanes, portable_math=True, forward_sum=True, sums=start.copy())
+        per = spp // lanes
+        for p in (0, 17, 95):
+            s = oracle.trace_samples(sc, cam, np.full(spp, p, np.uint32), np.arange(begin, begin + spp, dtype=np.uint32), seed, 100,
+                                     portable_math=True, forward_sum=True)
+            tot = None
+            for l in range(lanes):
+                part = np.zeros(3)
+                for row in s[l * per:(spp if l + 1 == lanes else (l + 1) * per)]:
+                    part = part + row
+                tot = part if tot is None else tot + part
+            assert np.array_equal(got.reshape(-1, 3)[p], start.reshape(-1, 3)[p] + tot), (lanes, p)
