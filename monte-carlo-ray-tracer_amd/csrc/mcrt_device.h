@@ -390,6 +390,17 @@ struct LdsStack {
     }
 };
 
+// Reciprocal of a direction component for the node slab tests.  A zero (or denormal) component would give
+// +-inf, and (face - origin) * inf is NaN when the origin lies exactly on a box face - min/max drop the NaN
+// and the node is culled although the ray runs inside it.  Clamped to +-FLT_MAX the product is 0 on the
+// face, +-huge off it: the slab is open for a parallel ray between the faces and closed outside them, which
+// is AABB::IntersectsRay's "skip the axis" (source/core/aabb.h:56) plus the containment the caller needs.
+MCRT_DEV float slab_rcp(float d)
+{
+    const float r = __frcp_rn(d);
+    return fabsf(r) <= kFltMax ? r : copysignf(kFltMax, d);
+}
+
 template <class PS, class PB, bool kCount> struct OctreeWalk {
     Hit best;
     uint64_t gate_known, gate_pass;
@@ -514,8 +525,8 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
     // return once fewer than refill/64 of the lanes that came in unfinished are still walking.
     template <class St> MCRT_DEV void run(PS sm, PB big, const SceneView& v, St& st, V3 o, V3 d, Counters& cn, uint32_t refill, uint32_t chunk = 0xFFFFFFFFu)
     {
-        // Node culling is conservative (boxes are padded at build time), so fast reciprocals are fine here.
-        const float ix = __frcp_rn(d.x), iy = __frcp_rn(d.y), iz = __frcp_rn(d.z);
+        // Node culling is conservative (boxes are padded at build time); reciprocals are clamped, see slab_rcp.
+        const float ix = slab_rcp(d.x), iy = slab_rcp(d.y), iz = slab_rcp(d.z);
         // visit octants front to back: flip the octant index on axes where the ray runs backwards
         const uint32_t flip = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
         const PB nodes = big + v.off_node;

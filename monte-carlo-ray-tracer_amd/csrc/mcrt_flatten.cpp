@@ -17,8 +17,9 @@
 //   - a primitive much larger than a child cell stays in the interior node's
 //     own list; the others go into every child whose cell the triangle itself
 //     (not just its box) overlaps;
-//   - every node stores the padded union of (member box  intersect  cell), so
-//     a float slab test on it can never cull a node holding the nearest hit.
+//   - every node stores the union of (padded member box  intersect  padded
+//     cell), so a float slab test on it can never cull a node holding the
+//     nearest hit - also not for a ray lying exactly in a split plane.
 #include "mcrt_flatten.h"
 
 #include <algorithm>
@@ -120,8 +121,14 @@ struct Builder {
             n.cell = cell;
             n.depth = depth;
             for (int c = 0; c < 8; ++c) n.child[c] = -1;
+            // clipped to the PADDED cell: a ray that runs exactly in a split plane (zero direction component, origin on
+            // the plane - every primary ray through the image centre column of a symmetric room) must find both
+            // neighbours' boxes open on that axis, and a hit point a rounding error away from the plane must lie
+            // strictly inside the box of the cell that holds it
+            Box padded_cell;
+            for (int a = 0; a < 3; ++a) { padded_cell.mn[a] = cell.mn[a] - pad; padded_cell.mx[a] = cell.mx[a] + pad; }
             n.tight = empty_box();
-            for (uint32_t p : members) grow(n.tight, clip(prim_box[p], cell));
+            for (uint32_t p : members) grow(n.tight, clip(prim_box[p], padded_cell));
         }
         deepest = std::max(deepest, depth);
 

@@ -39,6 +39,77 @@ def unit(v):
     return (v / n[:, None]).astype(F)
 
 
+def split_planes(flat, levels=3):
+    """Per axis, the octree split planes of the first `levels` levels exactly as mcrt_flatten.cpp computes them in
+    float32 (root cell = union of the primitive boxes grown by 2 * pad; centre = mn + 0.5f * (mx - mn), recursively).
+    The replicated padding is checked against the built tree: the root's stored box is the primitive union +- pad."""
+    tr = flat.triangles
+    pts = [tr["v0"], tr["v1"], tr["v2"]] if len(tr) else []
+    lo = np.min([p.min(axis=0) for p in pts], axis=0).astype(F)
+    hi = np.max([p.max(axis=0) for p in pts], axis=0).astype(F)
+    for o in flat.objects:
+        if o["kind"] == abi.OBJECT_SPHERE and o["radius"] >= np.finfo(F).eps:
+            r = F(abs(o["radius"]))
+            lo = np.minimum(lo, (o["position"] - r).astype(F)); hi = np.maximum(hi, (o["position"] + r).astype(F))
+    extent = F((hi - lo).max())
+    mag = F(max(np.abs(lo).max(), np.abs(hi).max()))
+    pad = max(F(1.0e-4) * max(extent, F(1.0e-3)), F(256.0) * np.finfo(F).eps * mag)
+    _, box, _, _ = pkg.build_scene_image(flat)
+    assert np.array_equal(box[0, :3], (lo - pad).astype(F)) and np.array_equal(box[0, 3:], (hi + pad).astype(F)), "pad rule out of step with mcrt_flatten.cpp"
+    mn, mx = (lo - F(2.0) * pad).astype(F), (hi + F(2.0) * pad).astype(F)
+    planes = []
+    for a in range(3):
+        cells, out = [(mn[a], mx[a])], []
+        for _ in range(levels):
+            nxt = []
+            for c0, c1 in cells:
+                mid = F(c0 + F(0.5) * F(c1 - c0))
+                out.append(mid); nxt += [(c0, mid), (mid, c1)]
+            cells = nxt
+        planes.append(np.array(sorted(set(out)), F))
+    return planes
+
+
+def split_plane_rays(R, cam, flat, rng, per_plane=48):
+    """Rays that lie exactly IN a split plane of the flat octree: origin on the plane, that direction component
+    +0, -0 or a denormal (reciprocal overflows), one or two zero components; plus the camera rays through the
+    image's centre column and centre row, whose direction has an exact zero when the camera looks down an axis.
+    (0 * inf = NaN in a node slab test culled both neighbours of the plane before round 2.)"""
+    os_, ds_ = [], []
+    planes = split_planes(flat)
+    lo = np.array([p.min() for p in planes], F); hi = np.array([p.max() for p in planes], F)
+    zero_like = np.array([0.0, -0.0, 1e-42, -1e-42], F)
+    for a in range(3):
+        for v in planes[a]:
+            o = rng.uniform(lo * F(1.3), hi * F(1.3), size=(per_plane, 3)).astype(F)
+            o[:, a] = v
+            d = unit(rng.normal(size=(per_plane, 3)))
+            d[:, a] = 0
+            q = per_plane // 4
+            d[q:2 * q, (a + 1) % 3] = 0                              # two zero components: axis-parallel, in the plane
+            o[2 * q:3 * q, (a + 1) % 3] = rng.choice(planes[(a + 1) % 3], q)   # on two planes at once (a cell edge)
+            d = unit(d)
+            d[:, a] = rng.choice(zero_like, per_plane)
+            d[q:2 * q, (a + 1) % 3] = rng.choice(zero_like, q)
+            os_.append(o); ds_.append(d.astype(F))
+    # origins on a plane, direction leaving it at a grazing angle (|component| from 1e-30 to 1e-3)
+    for a in range(3):
+        n = 8 * len(planes[a])
+        o = rng.uniform(lo * F(1.3), hi * F(1.3), size=(n, 3)).astype(F)
+        o[:, a] = np.repeat(planes[a], 8)
+        d = unit(rng.normal(size=(n, 3)))
+        d[:, a] = (rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-30, -3, n)).astype(F)
+        os_.append(o); ds_.append(d.astype(F))
+    # camera rays through the image centre (x == W/2 or y == H/2): what a jitter below 2^-14 produces
+    w, h = cam.width, cam.height
+    m = 192
+    xs = np.concatenate([np.full(m, w / 2), rng.uniform(0, w, m), [w / 2]]).astype(F)
+    ys = np.concatenate([rng.uniform(0, h, m), np.full(m, h / 2), [h / 2]]).astype(F)
+    co, cd = R.camera_rays(cam, xs, ys)
+    os_.append(co); ds_.append(cd)
+    return np.concatenate(os_).astype(F), np.concatenate(ds_).astype(F)
+
+
 def make_rays(R, scene, cam, flat, rng, n_random=6000, n_secondary=6000):
     """Primary grid + harvested secondary rays + random + adversarial rays."""
     os_, ds_ = [], []
@@ -118,6 +189,9 @@ def scene_fixture(R, name, scene, flat, lights):
 
 def hits_and_samples(R, name, scene, flat, cam, rng, n_samples):
     o, d = make_rays(R, scene, cam, flat, rng)
+    # round 2: rays in the octree's split planes; their own generator, so every other fixture keeps its bytes
+    so, sd = split_plane_rays(R, cam, flat, np.random.default_rng([20261111, len(name), n_samples]))
+    o, d = np.ascontiguousarray(np.concatenate([o, so])), np.ascontiguousarray(np.concatenate([d, sd]))
     obj, elem, t = R.intersect(scene, o, d)
     save(f"hits_{name}.npz", origins=o, dirs=d, obj=obj, elem=elem, t=t)
     npix = cam.width * cam.height
@@ -169,6 +243,18 @@ def main():
     pflat, plights = R.dump(point)
     scene_fixture(R, "cornell_point", point, pflat, plights)
     hits_and_samples(R, "cornell_point", point, pflat, cam512, rng, 1024)
+
+    # a sphere light with radius > 0: SphereObject::GetRandomPointOnSurface (source/objects/sphere.h:59-69) is sampled
+    # and the emitter itself can be hit (it is not IsLight(): shaded as a diffuse sphere, source/scene.cpp:103)
+    sflat = abi.FlatScene(pflat.objects.copy(), pflat.triangles.copy(), pflat.background)
+    li = int(plights[0])
+    assert sflat.objects["kind"][li] == abi.OBJECT_SPHERE
+    sflat.objects["radius"][li] = 0.6
+    sflat.objects["position"][li] = (0.5, 3.0, 0.25)
+    ssc = R.scene(sflat)
+    sflat2, slights = R.dump(ssc)
+    scene_fixture(R, "cornell_sphere_light", ssc, sflat2, slights)
+    hits_and_samples(R, "cornell_sphere_light", ssc, sflat2, cam512, np.random.default_rng(20261112), 2048)
 
     hexa = R.hexagon()
     hflat, hlights = R.dump(hexa)

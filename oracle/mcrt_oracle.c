@@ -937,7 +937,10 @@ ORC_EXPORT int orc_intersect_octree(const orc_scene* S, const orc_octree* T, uin
     for (uint64_t i = 0; i < n; ++i) {
         v3 ro = ld3(o + 3 * i), rd = ld3(d + 3 * i);
         uint64_t gate_known = 0, gate_pass = 0;
-        const float inv[3] = { 1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z };
+        /* slab_rcp of csrc/mcrt_device.h: the reciprocal clamped to +-FLT_MAX so that (face - origin) * inv is never NaN */
+        float inv[3] = { 1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z };
+        const float dd[3] = { rd.x, rd.y, rd.z };
+        for (int a = 0; a < 3; ++a) if (!(fabsf(inv[a]) <= FLT_MAX)) inv[a] = copysignf(FLT_MAX, dd[a]);
         const float oo[3] = { ro.x, ro.y, ro.z };
         const uint32_t flip = (rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u);
         hit_t best = { -1, 0, FLT_MAX };
