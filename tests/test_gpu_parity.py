@@ -75,11 +75,18 @@ def test_per_sample_radiance(backend, pkg, oracle, scene_of, golden, name):
     assert same.all(), f"{(~same).sum()} of {len(same)} samples differ from the oracle, first {np.flatnonzero(~same)[:5]}"
     # (2) against the reference's own numbers (glibc trig, recursion-order sums): a path can only
     # differ where a <=1-ulp trig difference exists; require 99 % of samples within 1e-9 relative.
+    # A sphere light runs acosf + two sincosf per light sample (source/objects/sphere.h:59-69), so there the
+    # 1-ulp differences reach 5 % of the samples, as a float-rounding-sized change of the light direction:
+    # 94 % within 1e-9 and 99.9 % within 1e-5 (glibc 2.35's acosf itself differs from the correctly rounded
+    # value on 7.7 % of inputs, its tanf on 3.9 %, sinf/cosf on 1.3 %: DESIGN.md section 4).
     ref = g["radiance"]
     scale = np.maximum(np.abs(ref).max(axis=1), 1e-3)
     rel = np.abs(got - ref).max(axis=1) / scale
-    ok = (rel < 1e-9) | (np.isnan(got).any(axis=1) & np.isnan(ref).any(axis=1))
-    assert ok.mean() > 0.99, f"only {ok.mean():.4f} of samples within 1e-9 of the reference"
+    both_nan = np.isnan(got).any(axis=1) & np.isnan(ref).any(axis=1)
+    ok = (rel < 1e-9) | both_nan
+    need = 0.94 if name == "cornell_sphere_light" else 0.99
+    assert ok.mean() > need, f"only {ok.mean():.4f} of samples within 1e-9 of the reference"
+    assert ((rel < 1e-5) | both_nan).mean() > 0.998
     assert abs(np.nanmean(got) - np.nanmean(ref)) < 0.02 * abs(np.nanmean(ref)) + 1e-6
 
 
