@@ -192,6 +192,22 @@ int mcrt_intersect_device(mcrt_ctx* ctx, uint64_t n, const float* d_origins,
                           const float* d_dirs, int32_t* d_obj, uint32_t* d_elem,
                           float* d_t);
 
+/* mcrt_intersect for callers that must not allocate device memory (code that
+ * runs under HIP graph capture next to it, tight serving loops, harnesses that
+ * forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same arguments, same
+ * results as mcrt_intersect, but the device staging of the five host arrays
+ * lives in a static device array of the library (MCRT_NOALLOC_MAX_RAYS * 36
+ * bytes, 14.4 MB, held by every GPU the library is used on until the process
+ * ends) instead of hipMalloc'ed buffers: the call makes no hipMalloc / hipFree.
+ * n > MCRT_NOALLOC_MAX_RAYS is refused with MCRT_ERR_LIMIT.  All contexts on
+ * one GPU share that GPU's staging array: calls that overlap in time on one
+ * GPU (two contexts, two threads) race - serialise them.  The array keeps the
+ * previous call's bytes; nothing in it needs clearing (every output of rays
+ * [0, n) is written before it is copied back). */
+#define MCRT_NOALLOC_MAX_RAYS 400000u
+int mcrt_intersect_noalloc(mcrt_ctx* ctx, uint64_t n, const float* origins, const float* dirs,
+                           int32_t* out_obj, uint32_t* out_elem, float* out_t);
+
 /* Per-sample radiance, i.e. one iteration of the spp loop of
  * source/main.cpp:122-139 without the Accumulate: jitter, GetPixelRay,
  * Scene::TraceRay (source/scene.cpp:94-234) with max_depth.  Sample k uses

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(HERE, "libmcrt_hip.so")
 # every symbol include/mcrt.h declares
 ABI_SYMBOLS = (
     "mcrt_create", "mcrt_destroy", "mcrt_last_error", "mcrt_set_stream", "mcrt_upload_scene", "mcrt_set_camera", "mcrt_set_accel",
-    "mcrt_camera_rays", "mcrt_intersect", "mcrt_intersect_device", "mcrt_trace_samples", "mcrt_trace_rays", "mcrt_render_unlit", "mcrt_rng_seed",
+    "mcrt_camera_rays", "mcrt_intersect", "mcrt_intersect_device", "mcrt_intersect_noalloc", "mcrt_trace_samples", "mcrt_trace_rays", "mcrt_render_unlit", "mcrt_rng_seed",
     "mcrt_clear", "mcrt_bind_accumulator", "mcrt_accumulator", "mcrt_render", "mcrt_last_render_ms", "mcrt_resolve",
     "mcrt_read_accumulator", "mcrt_write_accumulator", "mcrt_synchronize", "mcrt_octree_info_get", "mcrt_octree_download", "mcrt_set_counting", "mcrt_counters",
     "mcrt_lanes_per_pixel", "mcrt_set_lanes_per_pixel",
@@ -183,6 +183,14 @@ class Backend:
         n = len(o)
         obj = np.zeros(n, np.int32); elem = np.zeros(n, np.uint32); t = np.zeros(n, np.float32)
         self._ck(self.lib.mcrt_intersect(self.ctx, C.c_uint64(n), _ptr(o, C.c_float), _ptr(d, C.c_float), _ptr(obj, C.c_int32), _ptr(elem, C.c_uint32), _ptr(t, C.c_float)))
+        return obj, elem, t
+
+    def intersect_noalloc(self, origins, dirs):
+        """mcrt_intersect_noalloc: staging in the library's static device array, no device allocation."""
+        o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)
+        n = len(o)
+        obj = np.zeros(n, np.int32); elem = np.zeros(n, np.uint32); t = np.zeros(n, np.float32)
+        self._ck(self.lib.mcrt_intersect_noalloc(self.ctx, C.c_uint64(n), _ptr(o, C.c_float), _ptr(d, C.c_float), _ptr(obj, C.c_int32), _ptr(elem, C.c_uint32), _ptr(t, C.c_float)))
         return obj, elem, t
 
     def intersect_device(self, n, d_origins, d_dirs, d_obj, d_elem, d_t):

@@ -677,6 +677,14 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const double* __restrict__ s
 
 thread_local std::string g_create_error;
 
+// Staging area of mcrt_intersect_noalloc: device memory the library never allocates at run time.  One copy per GPU
+// (the code object is loaded once per device); every context on a device shares that device's copy.  In host code the
+// NAME is only a handle for hipGetSymbolAddress - the kernels get the device address looked up in mcrt_create.
+constexpr size_t kNoAllocSlot = ((size_t)MCRT_NOALLOC_MAX_RAYS * 12u + 255u) & ~(size_t)255u;   // one 3-float array, 256-byte aligned
+constexpr size_t kNoAllocSlotSmall = ((size_t)MCRT_NOALLOC_MAX_RAYS * 4u + 255u) & ~(size_t)255u;
+constexpr size_t kNoAllocBytes = 2 * kNoAllocSlot + 3 * kNoAllocSlotSmall;                      // origins, dirs | obj, elem, t
+static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
+
 } // namespace
 
 // ===================================================================== context
@@ -721,6 +729,7 @@ struct mcrt_ctx {
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    unsigned char* noalloc_scratch = nullptr;   // this device's copy of `scratch` (hipGetSymbolAddress in mcrt_create)
 };
 
 namespace {
@@ -922,6 +931,8 @@ int mcrt_create(int device_id, mcrt_ctx** out_ctx)
     if ((e = hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&c->d_tile, 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+    // with this context's device current: the address of THIS device's copy of the static staging array
+    if ((e = hipGetSymbolAddress((void**)&c->noalloc_scratch, HIP_SYMBOL(scratch))) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
     *out_ctx = c;
     return MCRT_OK;
 }
@@ -1088,6 +1099,35 @@ int mcrt_intersect(mcrt_ctx* c, uint64_t n, const float* o, const float* d, int3
     HIP_TRY(c, hipMemcpyAsync(out_obj, dobj.p, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(out_elem, delem.p, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(out_t, dt.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+
+int mcrt_intersect_noalloc(mcrt_ctx* c, uint64_t n, const float* o, const float* d, int32_t* out_obj, uint32_t* out_elem, float* out_t)
+{
+    int rc = need_scene(c, false);
+    if (rc) return rc;
+    if (n == 0) return MCRT_OK;
+    if (!o || !d || !out_obj || !out_elem || !out_t) return fail(c, MCRT_ERR_INVALID, "null buffer");
+    if (n > MCRT_NOALLOC_MAX_RAYS)
+        return fail(c, MCRT_ERR_LIMIT, "mcrt_intersect_noalloc: more than MCRT_NOALLOC_MAX_RAYS (" + std::to_string(MCRT_NOALLOC_MAX_RAYS) +
+                                           ") rays in one call; split the batch or use mcrt_intersect");
+    if (!c->noalloc_scratch) return fail(c, MCRT_ERR_STATE, "static staging area not resolved");
+    unsigned char* base = c->noalloc_scratch;      // never the array's name: that is a host-side stand-in
+    float* dor = reinterpret_cast<float*>(base);
+    float* ddi = reinterpret_cast<float*>(base + kNoAllocSlot);
+    int32_t* dobj = reinterpret_cast<int32_t*>(base + 2 * kNoAllocSlot);
+    uint32_t* delem = reinterpret_cast<uint32_t*>(base + 2 * kNoAllocSlot + kNoAllocSlotSmall);
+    float* dt = reinterpret_cast<float*>(base + 2 * kNoAllocSlot + 2 * kNoAllocSlotSmall);
+    // nothing in the staging area has to start at zero: the kernel writes all three outputs of every ray i < n,
+    // and only those are copied back
+    HIP_TRY(c, hipMemcpyAsync(dor, o, n * 12, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(ddi, d, n * 12, hipMemcpyHostToDevice, c->stream));
+    rc = mcrt_intersect_device(c, n, dor, ddi, dobj, delem, dt);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out_obj, dobj, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out_elem, delem, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out_t, dt, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MCRT_OK;
 }
