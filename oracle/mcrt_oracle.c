@@ -7,7 +7,7 @@
  * performs it.  Each function cites the reference lines it follows
  * (`source/...` is relative to the reference checkout).
  *
- * Pinning: tests/test_oracle_vs_golden.py checks this file bit-for-bit against
+ * Pinning: tests/test_oracle_golden.py checks this file bit-for-bit against
  * fixtures under tests/golden/ that oracle/gen_golden.py produced by running
  * the reference's own translation units (oracle/_ref, built by
  * oracle/Makefile from /root/reference).  The reference ships no tests or
@@ -95,7 +95,7 @@ static inline d3 ldd3(const double* p) { return D(p[0], p[1], p[2]); }
  * Used only when orc_options.portable_math != 0.  float functions evaluated
  * through double polynomials in a fixed operation order; the kernels in
  * csrc/ carry the same sequences, so device and host agree bit for bit.
- * Accuracy (checked in tests/test_portable_math.py): within 1 ulp of libm,
+ * Accuracy (checked in tests/test_host_and_abi.py::test_portable_trig_within_one_ulp_of_libm): within 1 ulp of libm,
  * equal to it on > 99.9 % of inputs.  Kernel coefficients are the classic
  * fdlibm minimax sets for sin/cos on [-pi/4, pi/4] and asin on [0, 0.5]. */
 static const double PM_PIO2_HI = 1.57079632679489655800e+00;
@@ -278,7 +278,11 @@ typedef struct orc_scene {
     mcrt_triangle* tri;
     uint32_t* lights;        /* Scene::lights: indices of emissive objects, source/scene.cpp:41-49 */
     d3 background;
+    struct orc_tree* tree;   /* optional: the product's flat octree, attached for the config-4 CPU baseline (see the replay section) */
 } orc_scene;
+struct orc_tree;
+static void orc_tree_free(struct orc_tree* t);
+ORC_EXPORT void orc_scene_detach_octree(orc_scene* s) { if (s->tree) { orc_tree_free(s->tree); s->tree = NULL; } }
 
 ORC_EXPORT orc_scene* orc_scene_create(const mcrt_scene_desc* d)
 {
@@ -299,6 +303,7 @@ ORC_EXPORT orc_scene* orc_scene_create(const mcrt_scene_desc* d)
 ORC_EXPORT void orc_scene_destroy(orc_scene* s)
 {
     if (!s) return;
+    orc_scene_detach_octree(s);
     free(s->obj); free(s->tri); free(s->lights); free(s);
 }
 ORC_EXPORT uint32_t orc_scene_lights(const orc_scene* s, int32_t* out)
@@ -503,8 +508,10 @@ static inline int sphere_hit(const mcrt_object* S, v3 o, v3 d, float* t)
 
 /* Scene::IntersectRay, source/scene.cpp:62-80, with TriangleMesh::Intersects,
  * source/objects/mesh.cpp:9-41. */
+static hit_t scene_hit_octree(const orc_scene* S, v3 o, v3 d, orc_stats* st);
 static inline hit_t scene_hit(const orc_scene* S, v3 o, v3 d, orc_stats* st)
 {
+    if (S->tree) return scene_hit_octree(S, o, d, st);
     hit_t best = { -1, 0, FLT_MAX };
     if (st) st->rays++;
     for (uint32_t i = 0; i < S->nobj; ++i) {
@@ -537,6 +544,151 @@ ORC_EXPORT void orc_intersect(const orc_scene* S, uint64_t n, const float* o, co
         hit_t h = scene_hit(S, ld3(o + 3 * i), ld3(d + 3 * i), st);
         out_obj[i] = h.obj; out_elem[i] = h.elem; out_t[i] = h.t;
     }
+}
+
+/* ------------------------------------------------------- flat-octree replay
+ * CPU replay of the product's flat octree traversal (cast_octree in
+ * monte-carlo-ray-tracer_amd/csrc/mcrt_device.h; layout in csrc/mcrt_layout.h)
+ * with visit counters.  The structure itself is product data (downloaded with
+ * mcrt_scene_image_octree / mcrt_octree_download); the leaf tests are this
+ * file's restatements, so `replay == orc_intersect` proves the structure can
+ * never hide the nearest hit, and the counters define the algorithmic bytes of
+ * SURVEY.md 8(d).  orc_scene_attach_octree makes scene_hit - and with it
+ * TraceRay and the render loop - query through the replay: the "restatement's
+ * octree path" that is the CPU baseline of BASELINE config 4, where the
+ * reference's brute force (10^6 triangle tests per ray) is not feasible. */
+typedef struct orc_octree {
+    uint32_t node_count;
+    const float* box;        /* node_count * 6: min xyz, max xyz (padded)            */
+    const uint32_t* words;   /* node_count * 2: child word (mask<<24 | first child), first prim ref */
+    const uint32_t* refs;    /* primitive ids, bit 31 = last of the node's list      */
+} orc_octree;
+
+typedef struct orc_octree_stats { uint64_t rays, nodes, tris, spheres, gates; } orc_octree_stats;
+
+struct orc_tree {
+    orc_octree view;
+    float* box; uint32_t* words; uint32_t* refs;      /* owned copies (attach) */
+    uint32_t* first_prim; uint32_t* prim_obj;         /* primitive ids are assigned in (object, element) order */
+};
+
+static void prim_tables(const orc_scene* S, uint32_t** first_prim_out, uint32_t** prim_obj_out)
+{
+    uint32_t nprim = 0;
+    uint32_t* first_prim = (uint32_t*)malloc(sizeof(uint32_t) * (S->nobj + 1));
+    for (uint32_t i = 0; i < S->nobj; ++i) { first_prim[i] = nprim; nprim += (S->obj[i].kind == MCRT_OBJECT_SPHERE) ? 1u : S->obj[i].triangle_count; }
+    first_prim[S->nobj] = nprim;
+    uint32_t* prim_obj = (uint32_t*)malloc(sizeof(uint32_t) * (nprim ? nprim : 1));
+    for (uint32_t i = 0; i < S->nobj; ++i) for (uint32_t p = first_prim[i]; p < first_prim[i + 1]; ++p) prim_obj[p] = i;
+    *first_prim_out = first_prim; *prim_obj_out = prim_obj;
+}
+
+static hit_t octree_hit(const orc_scene* S, const orc_octree* T, const uint32_t* first_prim, const uint32_t* prim_obj, v3 ro, v3 rd,
+                        orc_octree_stats* st, int* overflow)
+{
+    enum { STACK = 128 };
+    uint64_t gate_known = 0, gate_pass = 0;
+    /* slab_rcp of csrc/mcrt_device.h: the reciprocal clamped to +-FLT_MAX so that (face - origin) * inv is never NaN */
+    float inv[3] = { 1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z };
+    const float dd[3] = { rd.x, rd.y, rd.z };
+    for (int a = 0; a < 3; ++a) if (!(fabsf(inv[a]) <= FLT_MAX)) inv[a] = copysignf(FLT_MAX, dd[a]);
+    const float oo[3] = { ro.x, ro.y, ro.z };
+    const uint32_t flip = (rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u);
+    hit_t best = { -1, 0, FLT_MAX };
+    uint32_t bestPrim = 0xFFFFFFFFu;
+    uint32_t stack_node[STACK]; float stack_t[STACK];
+    int sp = 0;
+    stack_node[sp] = 0; stack_t[sp] = 0.0f; ++sp;
+    if (st) st->rays++;
+    while (sp > 0) {
+        --sp;
+        uint32_t node = stack_node[sp];
+        if (stack_t[sp] > best.t) continue;
+        if (st) st->nodes++;
+        uint32_t ref = T->words[2 * (size_t)node + 1];
+        if (ref != 0xFFFFFFFFu) {
+            uint32_t e;
+            do {
+                e = T->refs[ref++];
+                uint32_t prim = e & 0x7FFFFFFFu;
+                uint32_t ob = prim_obj[prim], el = prim - first_prim[ob];
+                const mcrt_object* O = &S->obj[ob];
+                float t = 0.0f; int h;
+                int better;
+                if (O->kind == MCRT_OBJECT_SPHERE) { if (st) st->spheres++; h = sphere_hit(O, ro, rd, &t); }
+                else {
+                    uint64_t bit = 1ull << ob;
+                    if (!(gate_known & bit)) {
+                        if (st) st->gates++;
+                        gate_known |= bit;
+                        if (aabb_hit(O->aabb_min, O->aabb_max, ro, rd)) gate_pass |= bit;
+                    }
+                    h = 0;
+                    if (gate_pass & bit) { if (st) st->tris++; h = tri_hit(&S->tri[O->first_triangle + el], ro, rd, &t); }
+                }
+                better = h && (t < best.t || (t == best.t && bestPrim != 0xFFFFFFFFu && prim < bestPrim));
+                if (better) { best.obj = (int32_t)ob; best.elem = el; best.t = t; bestPrim = prim; }
+            } while (!(e & 0x80000000u));
+        }
+        uint32_t cw = T->words[2 * (size_t)node];
+        uint32_t base = cw & 0x00FFFFFFu, mask = cw >> 24;
+        if (mask) {
+            for (int k = 7; k >= 0; --k) {
+                uint32_t oct = (uint32_t)k ^ flip;
+                if (!(mask & (1u << oct))) continue;
+                uint32_t child = base + (uint32_t)__builtin_popcount(mask & ((1u << oct) - 1u));
+                const float* b = T->box + 6 * (size_t)child;
+                float t0 = 0.0f, t1 = best.t;
+                for (int a = 0; a < 3; ++a) {
+                    float x = (b[a] - oo[a]) * inv[a], y = (b[3 + a] - oo[a]) * inv[a];
+                    t0 = fmaxf(t0, fminf(x, y)); t1 = fminf(t1, fmaxf(x, y));
+                }
+                if (t0 <= t1) { if (sp < STACK) { stack_node[sp] = child; stack_t[sp] = t0; ++sp; } else *overflow = 1; }
+            }
+        }
+    }
+    return best;
+}
+
+ORC_EXPORT int orc_intersect_octree(const orc_scene* S, const orc_octree* T, uint64_t n, const float* o, const float* d,
+                                    int32_t* out_obj, uint32_t* out_elem, float* out_t, orc_octree_stats* st)
+{
+    uint32_t *first_prim, *prim_obj;
+    prim_tables(S, &first_prim, &prim_obj);
+    int overflow = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        hit_t best = octree_hit(S, T, first_prim, prim_obj, ld3(o + 3 * i), ld3(d + 3 * i), st, &overflow);
+        out_obj[i] = best.obj; out_elem[i] = best.elem; out_t[i] = best.t;
+    }
+    free(first_prim); free(prim_obj);
+    return overflow;
+}
+
+/* From here on every nearest-hit query of this scene (orc_intersect, TraceRay, render) walks the given flat octree
+ * instead of the object list.  Same hits by construction (tests); different cost.  The arrays are copied. */
+ORC_EXPORT void orc_scene_attach_octree(orc_scene* S, const orc_octree* T, uint32_t ref_count)
+{
+    struct orc_tree* tr = (struct orc_tree*)calloc(1, sizeof *tr);
+    size_t nb = sizeof(float) * 6 * (size_t)T->node_count, nw = sizeof(uint32_t) * 2 * (size_t)T->node_count, nr = sizeof(uint32_t) * (size_t)(ref_count ? ref_count : 1);
+    tr->box = (float*)malloc(nb); tr->words = (uint32_t*)malloc(nw); tr->refs = (uint32_t*)malloc(nr);
+    memcpy(tr->box, T->box, nb); memcpy(tr->words, T->words, nw); memcpy(tr->refs, T->refs, sizeof(uint32_t) * (size_t)ref_count);
+    tr->view.node_count = T->node_count; tr->view.box = tr->box; tr->view.words = tr->words; tr->view.refs = tr->refs;
+    prim_tables(S, &tr->first_prim, &tr->prim_obj);
+    orc_scene_detach_octree(S);
+    S->tree = tr;
+}
+
+static hit_t scene_hit_octree(const orc_scene* S, v3 o, v3 d, orc_stats* st)
+{
+    int overflow = 0;
+    orc_octree_stats os = { 0, 0, 0, 0, 0 };
+    hit_t h = octree_hit(S, &S->tree->view, S->tree->first_prim, S->tree->prim_obj, o, d, st ? &os : NULL, &overflow);
+    if (st) { st->rays += os.rays; st->gates += os.gates; st->tri_tests += os.tris; st->sphere_tests += os.spheres; }
+    return h;
+}
+static void orc_tree_free(struct orc_tree* t)
+{
+    free(t->box); free(t->words); free(t->refs); free(t->first_prim); free(t->prim_obj); free(t);
 }
 
 /* ---------------------------------------------------------------- materials */
@@ -903,103 +1055,6 @@ ORC_EXPORT void orc_resolve(uint64_t npix, const double* sums, uint64_t spp, int
             out_bgra[4 * p + 3] = (uint8_t)(1.0 * 255.0);
         }
     }
-}
-
-/* ------------------------------------------------------- flat-octree replay
- * CPU replay of the product's flat octree traversal (cast_octree in
- * monte-carlo-ray-tracer_amd/csrc/mcrt_device.h; layout in csrc/mcrt_layout.h)
- * with visit counters.  The structure itself is product data (downloaded with
- * mcrt_scene_image_octree / mcrt_octree_download); the leaf tests are this
- * file's restatements, so `replay == orc_intersect` proves the structure can
- * never hide the nearest hit, and the counters define the algorithmic bytes of
- * SURVEY.md 8(d). */
-typedef struct orc_octree {
-    uint32_t node_count;
-    const float* box;        /* node_count * 6: min xyz, max xyz (padded)            */
-    const uint32_t* words;   /* node_count * 2: child word (mask<<24 | first child), first prim ref */
-    const uint32_t* refs;    /* primitive ids, bit 31 = last of the node's list      */
-} orc_octree;
-
-typedef struct orc_octree_stats { uint64_t rays, nodes, tris, spheres, gates; } orc_octree_stats;
-
-ORC_EXPORT int orc_intersect_octree(const orc_scene* S, const orc_octree* T, uint64_t n, const float* o, const float* d,
-                                    int32_t* out_obj, uint32_t* out_elem, float* out_t, orc_octree_stats* st)
-{
-    /* primitive ids are assigned in (object, element) order */
-    uint32_t nprim = 0;
-    uint32_t* first_prim = (uint32_t*)malloc(sizeof(uint32_t) * (S->nobj + 1));
-    for (uint32_t i = 0; i < S->nobj; ++i) { first_prim[i] = nprim; nprim += (S->obj[i].kind == MCRT_OBJECT_SPHERE) ? 1u : S->obj[i].triangle_count; }
-    first_prim[S->nobj] = nprim;
-    uint32_t* prim_obj = (uint32_t*)malloc(sizeof(uint32_t) * (nprim ? nprim : 1));
-    for (uint32_t i = 0; i < S->nobj; ++i) for (uint32_t p = first_prim[i]; p < first_prim[i + 1]; ++p) prim_obj[p] = i;
-    int overflow = 0;
-    enum { STACK = 128 };
-    for (uint64_t i = 0; i < n; ++i) {
-        v3 ro = ld3(o + 3 * i), rd = ld3(d + 3 * i);
-        uint64_t gate_known = 0, gate_pass = 0;
-        /* slab_rcp of csrc/mcrt_device.h: the reciprocal clamped to +-FLT_MAX so that (face - origin) * inv is never NaN */
-        float inv[3] = { 1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z };
-        const float dd[3] = { rd.x, rd.y, rd.z };
-        for (int a = 0; a < 3; ++a) if (!(fabsf(inv[a]) <= FLT_MAX)) inv[a] = copysignf(FLT_MAX, dd[a]);
-        const float oo[3] = { ro.x, ro.y, ro.z };
-        const uint32_t flip = (rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u);
-        hit_t best = { -1, 0, FLT_MAX };
-        uint32_t bestPrim = 0xFFFFFFFFu;
-        uint32_t stack_node[STACK]; float stack_t[STACK];
-        int sp = 0;
-        stack_node[sp] = 0; stack_t[sp] = 0.0f; ++sp;
-        if (st) st->rays++;
-        while (sp > 0) {
-            --sp;
-            uint32_t node = stack_node[sp];
-            if (stack_t[sp] > best.t) continue;
-            if (st) st->nodes++;
-            uint32_t ref = T->words[2 * (size_t)node + 1];
-            if (ref != 0xFFFFFFFFu) {
-                uint32_t e;
-                do {
-                    e = T->refs[ref++];
-                    uint32_t prim = e & 0x7FFFFFFFu;
-                    uint32_t ob = prim_obj[prim], el = prim - first_prim[ob];
-                    const mcrt_object* O = &S->obj[ob];
-                    float t = 0.0f; int h;
-                    int better;
-                    if (O->kind == MCRT_OBJECT_SPHERE) { if (st) st->spheres++; h = sphere_hit(O, ro, rd, &t); }
-                    else {
-                        uint64_t bit = 1ull << ob;
-                        if (!(gate_known & bit)) {
-                            if (st) st->gates++;
-                            gate_known |= bit;
-                            if (aabb_hit(O->aabb_min, O->aabb_max, ro, rd)) gate_pass |= bit;
-                        }
-                        h = 0;
-                        if (gate_pass & bit) { if (st) st->tris++; h = tri_hit(&S->tri[O->first_triangle + el], ro, rd, &t); }
-                    }
-                    better = h && (t < best.t || (t == best.t && bestPrim != 0xFFFFFFFFu && prim < bestPrim));
-                    if (better) { best.obj = (int32_t)ob; best.elem = el; best.t = t; bestPrim = prim; }
-                } while (!(e & 0x80000000u));
-            }
-            uint32_t cw = T->words[2 * (size_t)node];
-            uint32_t base = cw & 0x00FFFFFFu, mask = cw >> 24;
-            if (mask) {
-                for (int k = 7; k >= 0; --k) {
-                    uint32_t oct = (uint32_t)k ^ flip;
-                    if (!(mask & (1u << oct))) continue;
-                    uint32_t child = base + (uint32_t)__builtin_popcount(mask & ((1u << oct) - 1u));
-                    const float* b = T->box + 6 * (size_t)child;
-                    float t0 = 0.0f, t1 = best.t;
-                    for (int a = 0; a < 3; ++a) {
-                        float x = (b[a] - oo[a]) * inv[a], y = (b[3 + a] - oo[a]) * inv[a];
-                        t0 = fmaxf(t0, fminf(x, y)); t1 = fminf(t1, fmaxf(x, y));
-                    }
-                    if (t0 <= t1) { if (sp < STACK) { stack_node[sp] = child; stack_t[sp] = t0; ++sp; } else overflow = 1; }
-                }
-            }
-        }
-        out_obj[i] = best.obj; out_elem[i] = best.elem; out_t[i] = best.t;
-    }
-    free(first_prim); free(prim_obj);
-    return overflow;
 }
 
 ORC_EXPORT uint32_t orc_abi_sizes(uint32_t out[4])

@@ -201,6 +201,15 @@ class Oracle:
         assert overflow == 0, "traversal stack overflow in the replay"
         return obj, elem, t
 
+    def attach_octree(self, scene, node_box, node_words, prim_refs):
+        """Every later nearest-hit query of `scene` (intersect, trace, render) walks this flat octree (copied)."""
+        box, words, refs = _f32(node_box), _u32(node_words), _u32(prim_refs)
+        tree = OctreeView(len(box.reshape(-1, 6)), _p(box, C.c_float), _p(words, C.c_uint32), _p(refs, C.c_uint32))
+        self.lib.orc_scene_attach_octree(C.c_void_p(scene.h), C.byref(tree), C.c_uint32(len(refs)))
+
+    def detach_octree(self, scene):
+        self.lib.orc_scene_detach_octree(C.c_void_p(scene.h))
+
     def brdf(self, material, incident, reflection, normal, portable_math=False):
         i, r, n = _f32(incident).reshape(-1, 3), _f32(reflection).reshape(-1, 3), _f32(normal).reshape(-1, 3)
         out = np.zeros(len(i), np.float64)

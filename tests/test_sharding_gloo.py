@@ -57,6 +57,87 @@ def test_two_rank_sharded_render_equals_single_process(tmp_path, oracle, pkg, sc
     assert np.allclose(got, whole, rtol=1e-12, atol=1e-12)      # independent of N up to summation order
 
 
+def _progressive_worker(rank, world, port, out_path, scaling):
+    """bench.py's step(): passes, one reduce per pass, non-root ranks restart from zero, rank 0 keeps the running image."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+
+    import mcrt_pkg
+    import pyoracle as po
+    from mcrt_amd import sharding
+
+    pkg = mcrt_pkg.load()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc = po.Oracle()
+    sc = orc.scene(pkg.FlatScene.load(os.path.join(ROOT, "tests", "golden", "scene_cornell.npz")))
+    cam = orc.camera(16, 12, 90.0, (0, 0, 5), (0, 0, 0))
+    plan = sharding.SamplePlan(rank, world, 7, scaling, pass_spp=3)
+    acc = torch.zeros(12 * 16 * 3, dtype=torch.float64)
+    seen = []
+    for k, (first, count) in enumerate(plan.passes):
+        if count:
+            sums, _ = orc.render(orc.scene(sc.keep), cam, first, count, 100, 0x5EED0001, threads=1, portable_math=True, forward_sum=True,
+                                 sums=acc.numpy().reshape(12, 16, 3).copy())
+            acc = torch.from_numpy(sums.reshape(-1).copy())
+        sharding.reduce_accumulator(acc, dist, dst=0)
+        if k + 1 < len(plan.passes):
+            sharding.after_reduce(acc, dist, dst=0)
+        seen.append(plan.spp_after(k + 1))
+    dist.barrier()
+    if rank == 0:
+        np.savez(out_path, acc=acc.numpy(), seen=np.array(seen), total=plan.total_spp)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_progressive_passes_over_two_ranks(tmp_path, oracle, scene_of, scaling):
+    """Strong scaling (7 spp in total, 3-spp pass windows split over 2 ranks, one rank idle in the last window) and weak
+    scaling (7 spp per rank): rank 0 ends with the sum over every global sample index exactly once."""
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "acc.npz")
+    mp.spawn(_progressive_worker, args=(2, port, out, scaling), nprocs=2, join=True)
+    z = np.load(out)
+    total = int(z["total"])
+    assert total == (7 if scaling == "strong" else 14) and z["seen"][-1] == total
+    assert list(z["seen"]) == ([3, 6, 7] if scaling == "strong" else [6, 12, 14])
+    cam = oracle.camera(16, 12, 90.0, (0, 0, 5), (0, 0, 0))
+    whole, _ = oracle.render(oracle.scene(scene_of("cornell")), cam, 0, total, 100, 0x5EED0001, threads=2, portable_math=True, forward_sum=True)
+    assert np.allclose(z["acc"].reshape(12, 16, 3), whole, rtol=1e-12, atol=1e-12)
+
+
+def test_sample_plans_cover_every_index_once(pkg):
+    from mcrt_amd import sharding
+
+    for world in (1, 2, 3, 8):
+        for scaling, pass_spp in (("weak", None), ("strong", None), ("strong", 64), ("weak", 5), ("strong", 5)):
+            plans = [sharding.SamplePlan(r, world, 100, scaling, pass_spp) for r in range(world)]
+            assert len({len(p.passes) for p in plans}) == 1                  # every pass ends in a collective
+            covered = sorted(i for p in plans for b, n in p.passes for i in range(b, b + n))
+            total = plans[0].total_spp
+            assert covered == list(range(total)) and total == (100 * world if scaling == "weak" else 100)
+            assert plans[0].spp_after(len(plans[0].passes)) == total and plans[0].spp_after(0) == 0
+    assert sharding.split_range(10, 7, 3) == [(10, 3), (13, 2), (15, 2)]
+    with pytest.raises(ValueError):
+        sharding.SamplePlan(2, 2, 4)
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """bench.py --gpus N under a launcher that started another number of ranks exits non-zero before touching a GPU."""
+    import subprocess
+
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
 def test_rank_ranges_partition_the_samples(pkg):
     from mcrt_amd import sharding
 

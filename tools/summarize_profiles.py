@@ -1,50 +1,124 @@
-"""Turn the rocprofv3 outputs that a GPU run left under gpurun_out/ into the files kept under profiles/:
-kernel-trace stats CSVs, the FETCH_SIZE / WRITE_SIZE counter CSVs and r01_pmc_traffic.json (per-launch HBM bytes)."""
-import csv, glob, json, os, shutil, sys
+"""Turn the rocprofv3 outputs that tools/profile_pmc.sh left under gpurun_out/ into the files kept under profiles/:
+kernel-trace stats CSVs, the counter CSVs and <round>_pmc.json (per-sample instruction counts and HBM bytes of k_render,
+which bench.py reports with their source).
+
+  usage: python tools/summarize_profiles.py <tag> [<out-prefix>]     e.g.  r02  ->  profiles/r02_pmc.json
+
+Units and corrections (MI355X_MICROARCH.md, HBM / rocprofv3 sections): FETCH_SIZE and WRITE_SIZE are in KiB and summed
+over the XCDs; on gfx950 FETCH_SIZE reports half of the bytes read, so it is doubled; SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_*
+and SQ_BUSY_CYCLES count quad-cycles; every pass is a run of its own.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
-newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
-out = {}
-for w in ("config2_1024_256", "config4_1024_16", "cornell_512_64"):
-    vals = {}
-    for kind in ("fetch", "write"):
-        f = newest(os.path.join(G, f"{rnd}_{kind}_{w}", "*", "*_counter_collection.csv"))
-        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_render" in r["Kernel_Name"]]
-        full = sorted(x for x in v if x > 0.5 * max(v))          # the counting pass (8 spp) is the small one
-        vals[kind] = full[len(full) // 2]
-        shutil.copy(f, os.path.join(P, f"{rnd}_pmc_{kind}_size_{w}.csv"))
-    fetch, write = vals["fetch"] * 1024 * 2, vals["write"] * 1024
-    out[w] = {"fetch_bytes": int(fetch), "write_bytes": int(write), "traffic_bytes": int(fetch + write),
-              "raw_fetch_kib": vals["fetch"], "raw_write_kib": vals["write"]}
-# SQ pass: instruction counts of the full-spp k_render launches (median) and what they say about the VALU
-for w in list(out):
-    pat = os.path.join(G, f"{rnd}_sq_{w}", "*", "*_counter_collection.csv")
-    if not glob.glob(pat):
-        continue
-    f = newest(pat)
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+prefix = sys.argv[2] if len(sys.argv) > 2 else tag
+CUS, SIMDS, CLOCK = 256, 4, 2.4e9
+
+
+def newest(pat):
+    files = glob.glob(pat)
+    return max(files, key=os.path.getmtime) if files else None
+
+
+def render_rows(path):
+    """Per counter: [(value, seconds)] of the k_render dispatches of one pass."""
     per = {}
-    for r in csv.DictReader(open(f)):
+    for r in csv.DictReader(open(path)):
         if "k_render" in r["Kernel_Name"]:
             per.setdefault(r["Counter_Name"], []).append((float(r["Counter_Value"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9))
-    med = {}
-    for k, v in per.items():
-        full = sorted(x for x in v if x[0] > 0.5 * max(y[0] for y in v))
-        med[k] = full[len(full) // 2]
-    valu, secs = med["SQ_INSTS_VALU"]
-    out[w]["sq"] = {k: v[0] for k, v in med.items()}
-    out[w]["sq"]["kernel_s"] = secs
-    # 1024 SIMDs (256 CUs x 4), one wave64 VALU instruction occupies a SIMD for 4 cycles, 2.4 GHz peak engine clock
-    out[w]["valu_issue_busy"] = round(valu * 4 / (1024 * secs * 2.4e9), 3)
-    out[w]["active_lanes_per_valu_instruction"] = round(med["SQ_THREAD_CYCLES_VALU"][0] / valu, 1)
-    shutil.copy(f, os.path.join(P, f"{rnd}_pmc_sq_{w}.csv"))
-out["_notes"] = ("FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE undercounts by 2x (MI355X_MICROARCH.md, HBM/rocprofv3 "
-                 "section), corrected here. Per k_render launch, median over the full-spp launches of one bench.py run; separate --pmc passes. "
-                 "valu_issue_busy = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel time x 2.4 GHz).")
-json.dump(out, open(os.path.join(P, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
-for tag, src in (("config2", f"{rnd}_stats_c2"), ("config4", f"{rnd}_stats_c4")):
-    shutil.copy(newest(os.path.join(G, src, "*", "*_kernel_stats.csv")), os.path.join(P, f"{rnd}_kernel_stats_{tag}.csv"))
-for f in glob.glob(os.path.join(G, "fin_*.json")):
-    if os.path.getsize(f):
-        shutil.copy(f, os.path.join(P, f"{rnd}_bench_" + os.path.basename(f)[4:]))
+    return per
+
+
+def full_launch_median(rows):
+    """Median over the full-spp launches (bench.py also runs one short counting launch of 8 spp: the small one)."""
+    top = max(v for v, _ in rows)
+    full = sorted(x for x in rows if x[0] > 0.5 * top)
+    return full[len(full) // 2]
+
+
+out = {}
+workloads = sorted({os.path.basename(d)[len(tag) + 5:] for d in glob.glob(os.path.join(G, f"{tag}_sq1_*")) if os.path.isdir(d)})
+for w in workloads:
+    bench = None
+    try:
+        bench = json.loads(open(os.path.join(G, f"{tag}_stats_{w}.json")).read().strip().splitlines()[-1])
+    except (OSError, ValueError, IndexError):
+        pass
+    entry = {}
+    sq = {}
+    secs = None
+    for p in ("sq1", "sq2", "grbm"):
+        f = newest(os.path.join(G, f"{tag}_{p}_{w}", "*", "*_counter_collection.csv"))
+        if not f:
+            continue
+        for k, rows in render_rows(f).items():
+            v, s = full_launch_median(rows)
+            sq[k] = v
+            if k == "SQ_INSTS_VALU":
+                secs = s
+        shutil.copy(f, os.path.join(P, f"{prefix}_pmc_{p}_{w}.csv"))
+    for kind in ("fetch", "write"):
+        f = newest(os.path.join(G, f"{tag}_{kind}_{w}", "*", "*_counter_collection.csv"))
+        if not f:
+            continue
+        rows = [x for rows in render_rows(f).values() for x in rows]
+        v, _ = full_launch_median(rows)
+        entry[f"raw_{kind}_kib"] = v
+        entry[f"{kind}_bytes"] = int(v * 1024 * (2 if kind == "fetch" else 1))
+        shutil.copy(f, os.path.join(P, f"{prefix}_pmc_{kind}_size_{w}.csv"))
+    f = newest(os.path.join(G, f"{tag}_stats_{w}", "*", "*_kernel_stats.csv"))
+    if f:
+        shutil.copy(f, os.path.join(P, f"{prefix}_kernel_stats_{w}.csv"))
+    if bench:
+        json.dump(bench, open(os.path.join(P, f"{prefix}_bench_{w}.json"), "w"))
+    # samples of one full launch: from the bench line of the stats pass (same command)
+    samples = None
+    if bench:
+        import re
+
+        m = re.search(r"(\d+)x(\d+), (\d+) spp", bench["config"]["workload"])
+        if m:
+            samples = int(m.group(1)) * int(m.group(2)) * int(m.group(3)) // max(1, bench["config"].get("passes_per_step", 1))
+    entry["samples_per_launch"] = samples
+    entry["sq"] = sq
+    entry["kernel_s_in_sq1_pass"] = secs
+    if "fetch_bytes" in entry and "write_bytes" in entry:
+        entry["traffic_bytes"] = entry["fetch_bytes"] + entry["write_bytes"]
+        if samples:
+            entry["traffic_bytes_per_sample"] = entry["traffic_bytes"] / samples
+    if "SQ_INSTS_VALU" in sq:
+        valu = sq["SQ_INSTS_VALU"]
+        if samples:
+            entry["valu_insts_per_sample"] = valu / samples
+        if "SQ_THREAD_CYCLES_VALU" in sq:
+            entry["active_lanes_per_valu_instruction"] = round(sq["SQ_THREAD_CYCLES_VALU"] / valu, 2)
+        if secs:
+            # issue-slot utilisation in the profiled launch itself: 2 cycles per wave64 instruction on a SIMD-32
+            entry["valu_frac_in_profile"] = round(valu * 2 / (CUS * SIMDS * CLOCK * secs), 4)
+            # the same with the documented slower rates: f64 at half rate (4 cycles), transcendentals at quarter rate (8)
+            f64 = sum(sq.get(k, 0.0) for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64"))
+            trans = sq.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+            if f64 or trans:
+                entry["valu_cycle_weighted_frac"] = round((valu * 2 + f64 * 2 + trans * 6) / (CUS * SIMDS * CLOCK * secs), 4)
+        if "SQ_WAVE_CYCLES" in sq:
+            for k in ("SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY"):
+                if k in sq:
+                    entry[k.lower() + "_over_wave_cycles"] = round(sq[k] / sq["SQ_WAVE_CYCLES"], 4)
+    if "GRBM_GUI_ACTIVE" in sq and secs:
+        entry["effective_clock_ghz"] = round(sq["GRBM_GUI_ACTIVE"] / 8 / secs / 1e9, 3)
+    out[w] = entry
+out["_notes"] = ("Per k_render launch (median over the full-spp launches of one `bench.py --workload W` run per rocprofv3 pass; passes are separate "
+                 "runs: sq1, sq2, FETCH_SIZE, WRITE_SIZE, GRBM_GUI_ACTIVE, kernel-trace stats). FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is "
+                 "doubled (gfx950 reports half the bytes read, MI355X_MICROARCH.md). valu_frac_in_profile = SQ_INSTS_VALU x 2 cycles / "
+                 "(256 CUs x 4 SIMDs x 2.4 GHz x the launch's duration in the sq1 pass); valu_cycle_weighted_frac adds 2 more cycles per f64 "
+                 "instruction (half rate) and 6 more per f32 transcendental (quarter rate). bench.py uses valu_insts_per_sample and "
+                 "traffic_bytes_per_sample with the kernel time it measures itself.")
+json.dump(out, open(os.path.join(P, f"{prefix}_pmc.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
