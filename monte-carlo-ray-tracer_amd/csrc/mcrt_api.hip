@@ -167,7 +167,17 @@ struct ExplicitStart {
 // order plus the number dropped (Work::done; keep_nonfinite: the raw value, used by the parity path
 // with s_count == 1).  Lanes fetch on their own: a lane that finishes early does not wait for its
 // wavefront.
-template <class PS, class PB, int kAccel, bool kCount, class Work>
+//
+// A wavefront executes every piece of code that ANY of its lanes needs in an iteration, and with 64 lanes in 64
+// different path states that is nearly all of it, every iteration: the cost of the loop is its static size.  So the
+// shading of a diffuse hit is laid out to exist once: everything that follows from the hit alone - the light sample,
+// the roulette draw, the hemisphere bounce, the BRDF towards the light AND towards the bounce (brdf2: one copy of the
+// Oren-Nayar trigonometry serves both) - is computed when the hit is shaded, in the reference's draw order
+// (scene.cpp:127-164: light points, roulette, hemisphere; the shadow ray consumes no random numbers, so its outcome
+// cannot move a draw).  What waits for the shadow query is one comparison and one multiply-add.
+// kMulti: scenes with more than one light test the further lights one query at a time from a saved copy of the
+// generator (the state that path needs is compiled out of the one-light kernels).
+template <class PS, class PB, int kAccel, bool kCount, bool kMulti, class Work>
 __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, const CameraDev& cam, uint64_t seed, uint32_t max_depth,
                                            const PendStack& pend, bool keep_nonfinite, Counters& cn, RenderCounters& rc, Work& work,
                                            uint32_t refill, uint32_t* walk_lds)
@@ -186,9 +196,17 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
     D3 imp = dmk(1, 1, 1), L = dmk(0, 0, 0);
     uint32_t depth = 0, npend = 0;
     // diffuse-hit context kept across the shadow queries
-    V3 hp = mk(0, 0, 0), hn = mk(0, 0, 0), hd = mk(0, 0, 0);
+    V3 hp = mk(0, 0, 0), bd = mk(0, 0, 0);        // hit point (origin of the shadow rays and of the bounce), bounce direction
+    D3 impc = dmk(0, 0, 0);                        // importance * surface colour, scene.cpp:148
     D3 direct = dmk(0, 0, 0);
-    uint32_t horec = 0, light_i = 0;
+    double p_survive = 1.0, g_bounce = 0.0;       // roulette threshold; 2 * cosTheta * BRDF(bounce), scene.cpp:164
+    double w_light = 0.0;                          // BRDF(light) * surfaceDot * lightDot of the light under test, scene.cpp:136-139
+    bool survive = false;
+    uint32_t light_i = 0;
+    // kMulti only: what sampling and shading a further light needs
+    V3 hn = mk(0, 0, 0), hd = mk(0, 0, 0);
+    uint32_t horec = 0;
+    Rng g_l; g_l.s0 = 0; g_l.s1 = 0;
 
     // Octree path: the nearest-hit query is resumable (OctreeWalk): lanes whose ray is finished are shaded
     // and given their next ray while the others stay in mid-traversal.
@@ -199,9 +217,23 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
     WalkStackFor<PB>::bind(walk_stack, walk_lds);
     bool walking = false;
     if (kWalk) walk.idle();
+#ifndef MCRT_MIN_TRACE
+#define MCRT_MIN_TRACE 36
+#endif
+    constexpr uint32_t kMinTrace = kWalk ? 0u : (uint32_t)MCRT_MIN_TRACE;
+    // Fetch policy.  kFetchMin == 1: a lane takes its next item the moment it runs dry (octree walks: long, incoherent queries).
+    // Otherwise idle lanes wait until kFetchMin of them can fetch together (or nobody is left working): they then receive
+    // consecutive items - neighbouring pixels of one tile - which keeps the wavefront's rays coherent (the wave-uniform scan
+    // culls whole meshes per wavefront) without making everybody wait for the slowest lane of a 64-item round (kFetchMin == 64).
+    constexpr uint32_t kFetchMin = kWalk ? 1u : Work::kFetchMin;
 
     while (state != ST_DONE) {
-        if (state == ST_FETCH) {
+        bool fetch_ok = true;
+        if (kFetchMin > 1u) {
+            const uint64_t in_loop = __ballot(1), want = __ballot(state == ST_FETCH);
+            fetch_ok = (uint32_t)__popcll(want) >= kFetchMin || want == in_loop;
+        }
+        if (state == ST_FETCH && fetch_ok) {
             if (!work.next(pixel, s_begin, s_count)) { state = ST_DONE; continue; }
             ex = work.explicit_start(exs) ? &exs : nullptr;
             px = pixel % cam.width; py = pixel / cam.width;
@@ -239,11 +271,29 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
             walking = false;
             hit = walk.best;
         } else {
-            hit = cast<kAccel, PS, PB, kCount>(sm, big, v, ro, rd, cn);
+            // Batching of the shading: a lane with a shadow ray is always served (what follows its query is one comparison and a
+            // multiply-add); lanes with a camera / bounce ray are served when at least kMinTrace of them are waiting (or nobody has
+            // a shadow ray), otherwise they sit this query out - after it every shadow lane has turned into a trace lane, so the
+            // wait is one iteration.  The wavefront executes the whole shading of a hit whenever ANY lane needs it; this way it pays
+            // for that about every other iteration, with most of its lanes in it, instead of every iteration for a minority.
+            // Break-even by the instruction counts (cast ~2050, shading ~1200 per wavefront): wait when fewer than ~3/8 of the lanes are ready;
+            // measured optimum of the threshold over configs 1, 2, 3 and 5: 36 (sweep 0 / 12 / 24 / 36 / 64, profiles/r02_sweep_min_trace.txt).
+            bool live = state != ST_FETCH;          // a lane waiting for an item has no ray
+            if (kMinTrace > 0 && live) {
+                const bool is_s = state == ST_SHADOW;
+                const uint32_t n_s = (uint32_t)__popcll(__ballot(is_s)), n_t = (uint32_t)__popcll(__ballot(!is_s));
+                live = is_s || n_t >= kMinTrace || n_s == 0u;
+            }
+            hit = cast<kAccel, PS, PB, kCount>(sm, big, v, ro, rd, cn, live);
+            if (!live) continue;
         }
 
         bool branch_done = false;      // this TraceRay chain returned; continue with a parked branch or finish the sample
-        bool after_lights = false;
+        bool lights_done = false;      // every light of the current diffuse hit is accounted for
+        bool eval_light = false, eval_bounce = false;   // BRDF values wanted this iteration: towards `ldir`, towards `bd`
+        V3 ldir = mk(0, 0, 0), en = mk(0, 0, 0), ed = mk(0, 0, 0);   // light direction; normal and incident direction of the hit being shaded
+        uint32_t eorec = 0;
+        float cosTheta = 0.0f;
         if (state == ST_TRACE) {
             if (kCount) rc.trace_calls++;
             if (hit.obj == MISS) {
@@ -261,15 +311,27 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
                     const uint32_t surface = sm[orec + OBJ_SURFACE];
                     if (surface == MCRT_SURFACE_DIFFUSE) {
                         p = p + n * kMargin;                                // scene.cpp:115
-                        hp = p; hn = n; hd = rd; horec = orec;
+                        hp = p; en = n; ed = rd; eorec = orec;
                         direct = dmk(0.0, 0.0, 0.0);
                         light_i = 0;
-                        if (v.nlights == 0) after_lights = true;
+                        // the draws of scene.cpp:127-163 in their order: a point on every light, the roulette, the hemisphere
+                        if (v.nlights == 0) lights_done = true;
                         else {
                             const uint32_t lrec = v.off_obj + sm[v.off_lights] * OBJ_STRIDE;
-                            V3 ldir = normalize(light_point(sm, lrec, g) - hp);   // scene.cpp:129-130
-                            ro = hp; rd = ldir;
-                            state = ST_SHADOW;
+                            ldir = normalize(light_point(sm, lrec, g) - hp);      // scene.cpp:129-130
+                            eval_light = true;
+                            if constexpr (kMulti) {
+                                hn = n; hd = rd; horec = orec;
+                                g_l = g;                                          // the further lights are sampled from here, later
+                                for (uint32_t l = 1; l < v.nlights; ++l) light_skip(sm, v.off_obj + sm[v.off_lights + l] * OBJ_STRIDE, g);
+                            }
+                        }
+                        p_survive = max_importance(imp);                    // scene.cpp:147, before the colour
+                        impc = imp * ldd3(sm, orec + OBJ_COLOR);            // scene.cpp:148
+                        survive = !((0.0 + (1.0 - 0.0) * rng_double(g)) > p_survive);   // scene.cpp:150
+                        if (survive) {
+                            bd = hemisphere(n, g, cosTheta);                // scene.cpp:163
+                            eval_bounce = true;
                         }
                     } else if (surface == MCRT_SURFACE_SPECULAR) {
                         p = p + n * kMargin;                                // scene.cpp:171
@@ -288,8 +350,10 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
                         const float nr = n1 / n2;
                         const float cosI = dot(I, n);
                         const float cos2t = 1.0f - nr * nr * (1.0f - cosI * cosI);
+                        // the reflected ray serves total internal reflection, the parked branch of a split and the single choice
+                        const V3 refl_o = p + errorMargin, refl_d = reflect(I, n);
                         if (cos2t < 0.0f) {                                 // total internal reflection, scene.cpp:194-198
-                            ro = p + errorMargin; rd = reflect(I, n); depth -= 1;
+                            ro = refl_o; rd = refl_d; depth -= 1;
                         } else {
                             const V3 tdir = I * nr - n * (cosI * nr + sqrtf(cos2t));   // scene.cpp:202
                             float R0 = (n2 - n1) / (n2 + n1);
@@ -299,9 +363,8 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
                             if (rng_double(g) < max_importance(imp)) {      // scene.cpp:209-214: trace both
                                 // park the reflect branch, run the refract branch first (the order g++ evaluates
                                 // the two operands of the `+` at scene.cpp:212-213; pinned by fixture F5)
-                                const V3 po = p + errorMargin, pd = reflect(I, n);
                                 const D3 pimp = imp * (double)R;
-                                pend.push(npend, po, pd, pimp, depth - 1);
+                                pend.push(npend, refl_o, refl_d, pimp, depth - 1);
                                 npend += 1;
                                 if (kCount) rc.splits++;
                                 imp = imp * (double)(1.0 - R);
@@ -310,7 +373,7 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
                                 const double P = .25 + .5 * R;              // scene.cpp:218-228
                                 if (rng_double(g) < P) {
                                     imp = imp * (R / P);
-                                    ro = p + errorMargin; rd = reflect(I, n); depth -= 1;
+                                    ro = refl_o; rd = refl_d; depth -= 1;
                                 } else {
                                     imp = imp * ((1.0 - R) / (1.0 - P));
                                     ro = p - errorMargin; rd = tdir; depth -= 1;
@@ -322,36 +385,40 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
                     }
                 }
             }
-        } else {   // ST_SHADOW: the query was a shadow ray, scene.cpp:133-141
+        } else {   // ST_SHADOW: the query was the shadow ray towards light `light_i`, scene.cpp:133-141
             const uint32_t lobj = sm[v.off_lights + light_i];
-            if (hit.obj == MISS || hit.obj == lobj) {
-                const uint32_t lrec = v.off_obj + lobj * OBJ_STRIDE;
-                const float surfaceDot = dot(hn, rd);
-                const float lightDot = dot(mk(0.0f, -1.0f, 0.0f), rd * -1.0f);
-                const double f = brdf(sm, horec, hd, rd, hn);
-                direct = direct + ldd3(sm, lrec + OBJ_EMISSION) * (double)(f * surfaceDot * lightDot);
-            }
+            if (hit.obj == MISS || hit.obj == lobj) direct = direct + ldd3(sm, v.off_obj + lobj * OBJ_STRIDE + OBJ_EMISSION) * w_light;
             light_i += 1;
-            if (light_i < v.nlights) {
+            if (kMulti && light_i < v.nlights) {
                 const uint32_t lrec = v.off_obj + sm[v.off_lights + light_i] * OBJ_STRIDE;
-                V3 ldir = normalize(light_point(sm, lrec, g) - hp);
-                ro = hp; rd = ldir;
-            } else after_lights = true;
+                ldir = normalize(light_point(sm, lrec, g_l) - hp);
+                en = hn; ed = hd; eorec = horec;
+                eval_light = true;
+            } else lights_done = true;
         }
 
-        if (after_lights) {
-            // Russian roulette and the diffuse bounce, scene.cpp:147-167
-            const double p = max_importance(imp);
-            imp = imp * ldd3(sm, horec + OBJ_COLOR);
-            direct = direct * imp;
+        if (eval_light || eval_bounce) {
+            double f_light, f_bounce;
+            brdf2(sm, eorec, ed, en, eval_light, ldir, eval_bounce, bd, f_light, f_bounce);
+            if (eval_light) {
+                const float surfaceDot = dot(en, ldir);
+                const float lightDot = dot(mk(0.0f, -1.0f, 0.0f), ldir * -1.0f);
+                w_light = (double)(f_light * surfaceDot * lightDot);        // scene.cpp:136-139
+                ro = hp; rd = ldir;
+                state = ST_SHADOW;
+            }
+            if (eval_bounce) g_bounce = 2.0 * (double)cosTheta * f_bounce;  // scene.cpp:164
+        }
+
+        if (lights_done) {
+            // Russian roulette and the diffuse bounce, scene.cpp:147-167 (the draws were made when the hit was shaded)
+            direct = direct * impc;
             L = L + direct;
-            if ((0.0 + (1.0 - 0.0) * rng_double(g)) > p) branch_done = true;
+            if (!survive) branch_done = true;
             else {
-                imp = ddivs(imp, p);
-                float cosTheta;
-                const V3 bounce = hemisphere(hn, g, cosTheta);
-                imp = imp * (2.0 * (double)cosTheta * brdf(sm, horec, hd, bounce, hn));
-                ro = hp; rd = bounce; depth -= 1;
+                imp = ddivs(impc, p_survive);
+                imp = imp * g_bounce;
+                ro = hp; rd = bd; depth -= 1;
                 state = ST_TRACE;
             }
         }
@@ -411,17 +478,13 @@ __device__ __forceinline__ void flush_counters(unsigned long long* out, const Co
 // pixels alone cannot fill the GPU): the slice sums go to `partial` and k_combine adds them in slice order - the
 // summation order is fixed by (width, height, s_count) alone, never by scheduling.
 //
-// kRounds: the wavefront fetches in rounds - k_render takes 64 consecutive items (one tile of one slice) for the
-// whole wavefront, every lane works its item off, then the wavefront fetches again - which keeps its 64 lanes on
-// one tile (coherent rays: the wave-uniform scan culls whole meshes per wavefront; measured 9 % faster than
-// free-running lanes on the Cornell configurations).  Otherwise lanes fetch on their own whenever they run dry
-// (long incoherent walks through a big octree, where waiting for the slowest lane costs more than coherence gains).
-template <bool kRounds> struct RenderWork {
+// Lanes that run dry fetch together (trace_lane waits until kFetchMin of them can, Work::kFetchMin): one atomic per
+// wavefront and fetch, consecutive items - pixels of one tile - for the lanes that take part.
+template <uint32_t kFetchMinT> struct RenderWork {
+    static constexpr uint32_t kFetchMin = kFetchMinT;
     const RenderArgs& a;
     uint32_t slice;
     uint32_t dropped_total;
-    uint32_t item;        // kRounds: this lane's item of the current round
-    bool armed;
     __device__ __forceinline__ bool decode(uint32_t i, uint32_t& pixel, uint32_t& s_begin, uint32_t& s_count)
     {
         // a wavefront's 64 items: (64 >> wave_slices_log2) pixels of one small tile x (1 << wave_slices_log2) slices
@@ -441,11 +504,6 @@ template <bool kRounds> struct RenderWork {
     }
     __device__ __forceinline__ bool next(uint32_t& pixel, uint32_t& s_begin, uint32_t& s_count)
     {
-        if (kRounds) {
-            if (!armed) return false;
-            armed = false;
-            return decode(item, pixel, s_begin, s_count);
-        }
         for (;;) {
             // one atomic per wavefront for all lanes fetching together
             const uint64_t fetching = __ballot(1);
@@ -473,7 +531,7 @@ template <bool kRounds> struct RenderWork {
     }
 };
 
-template <bool kBigLds, int kAccel, bool kCount>
+template <bool kBigLds, int kAccel, bool kCount, bool kMulti>
 __global__ __launch_bounds__(kBlock, 4) void k_render(const RenderArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -489,21 +547,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_render(const RenderArgs a)
     pend.lane = blockIdx.x * blockDim.x + threadIdx.x;
     Counters cn = { 0, 0, 0, 0, 0 };
     RenderCounters rc = { 0, 0, 0 };
-    constexpr bool kRounds = kBigLds || kAccel == MCRT_ACCEL_SCAN || kAccel == MCRT_ACCEL_FLAT;
-    RenderWork<kRounds> work = { a, 0u, 0u, 0u, false };
-    if (kRounds) {
-        const uint32_t lane = threadIdx.x & 63u;
-        for (;;) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(a.tile_counter, 64u);
-            base = (uint32_t)__shfl((int)base, 0);
-            if (base >= a.items) break;                      // wave-uniform
-            work.item = base + lane; work.armed = true;
-            trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, false, cn, rc, work, a.refill, walk_lds);
-        }
-    } else {
-        trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, false, cn, rc, work, a.refill, walk_lds);
-    }
+#ifndef MCRT_FETCH_MIN
+#define MCRT_FETCH_MIN 64
+#endif
+    // scan / flat / LDS-resident variants keep their lanes on few tiles (coherent rays); walks through an HBM-resident octree run free
+    constexpr uint32_t kFetchMin = (kBigLds || kAccel == MCRT_ACCEL_SCAN || kAccel == MCRT_ACCEL_FLAT) ? (uint32_t)MCRT_FETCH_MIN : 1u;
+    RenderWork<kFetchMin> work = { a, 0u, 0u };
+    trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount, kMulti>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, false, cn, rc, work, a.refill, walk_lds);
     if (work.dropped_total) atomicAdd(a.tile_counter + 1, work.dropped_total);
     if (kCount) flush_counters(a.counters, cn, rc);
 }
@@ -540,6 +590,7 @@ struct ListArgs {
 
 // Work items of mcrt_trace_samples / mcrt_trace_rays: entry i of the caller's arrays, grid-strided per lane.
 struct ListWork {
+    static constexpr uint32_t kFetchMin = 1;
     const ListArgs& a;
     uint64_t i, stride, cur;
     __device__ __forceinline__ bool next(uint32_t& pixel, uint32_t& s_begin, uint32_t& s_count)
@@ -564,7 +615,7 @@ struct ListWork {
     }
 };
 
-template <bool kBigLds, int kAccel, bool kCount>
+template <bool kBigLds, int kAccel, bool kCount, bool kMulti>
 __global__ __launch_bounds__(kBlock) void k_trace_list(const ListArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -580,7 +631,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_list(const ListArgs a)
     Counters cn = { 0, 0, 0, 0, 0 };
     RenderCounters rc = { 0, 0, 0 };
     ListWork work = { a, pend.lane, (uint64_t)gridDim.x * blockDim.x, 0 };
-    trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, true, cn, rc, work, a.refill, walk_lds);
+    trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount, kMulti>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, true, cn, rc, work, a.refill, walk_lds);
     if (kCount) flush_counters(a.counters, cn, rc);
 }
 
@@ -799,9 +850,10 @@ template <class K> int set_lds_limit(mcrt_ctx* c, K kernel, size_t bytes)
     return MCRT_OK;
 }
 
+// One-light kernels (every BASELINE scene) exist for the timed builds; counting builds and scenes with several lights use the general ones.
 template <bool kBigLds, int kAccel, bool kCount> int launch_render_t(mcrt_ctx* c, const RenderArgs& a)
 {
-    auto kern = k_render<kBigLds, kAccel, kCount>;
+    auto kern = (kCount || c->view.nlights > 1) ? k_render<kBigLds, kAccel, kCount, true> : k_render<kBigLds, kAccel, kCount, kCount>;
     int rc = set_lds_limit(c, kern, lds_for(c));
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(grid_for(c)), dim3(kBlock), lds_for(c), c->stream, a);
@@ -810,7 +862,7 @@ template <bool kBigLds, int kAccel, bool kCount> int launch_render_t(mcrt_ctx* c
 }
 template <bool kBigLds, int kAccel, bool kCount> int launch_list_t(mcrt_ctx* c, const ListArgs& a)
 {
-    auto kern = k_trace_list<kBigLds, kAccel, kCount>;
+    auto kern = (kCount || c->view.nlights > 1) ? k_trace_list<kBigLds, kAccel, kCount, true> : k_trace_list<kBigLds, kAccel, kCount, kCount>;
     int rc = set_lds_limit(c, kern, lds_for(c));
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(grid_for(c)), dim3(kBlock), lds_for(c), c->stream, a);

@@ -165,7 +165,10 @@ MCRT_DEV void pm_sincos_d(float xf, double& s, double& c)
     else if (q == 2) { s = -sr; c = -cr; }
     else { s = -cr; c = sr; }
 }
-MCRT_DEV float pm_nan(float x) { return (x - x) / (x - x); }
+// (x - x) / (x - x) of the libm sources for an argument outside the domain: a quiet NaN.  Every caller has already
+// established that x is NaN, infinite or out of range, so the division itself (a dozen instructions per site) is skipped;
+// sign and payload of a NaN are not part of any comparison (non-finite samples are dropped, tests compare with isnan).
+MCRT_DEV float pm_nan(float) { return __builtin_nanf(""); }
 MCRT_DEV float pm_sinf(float x)
 {
     if (!(fabsf(x) <= 8192.0f)) return pm_nan(x);
@@ -206,24 +209,35 @@ MCRT_DEV double pm_asin_r(double z)
 }
 MCRT_DEV float pm_acosf(float xf)
 {
+    // Three argument ranges (|x| < 0.5, x <= -0.5, x >= 0.5), each with the operation sequence the oracle's pm_acosf has,
+    // but ONE evaluation of the rational R(z) and one square root shared by selects: a wavefront whose lanes fall into
+    // different ranges executes the expensive part once instead of three times.
     const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17, PI = 3.14159265358979311600e+00;
-    double x = (double)xf;
-    if (!(fabs(x) <= 1.0)) return (float)((x - x) / (x - x));
-    if (fabs(x) < 0.5) {
-        double z = x * x;
-        double a = x + x * pm_asin_r(z);
-        return (float)((PIO2_HI - a) + PIO2_LO);
-    }
-    if (x < 0.0) {
-        double z = (1.0 + x) * 0.5;
-        double s = sqrt(z);
-        double a = s + s * pm_asin_r(z);
-        return (float)(PI - 2.0 * a);
-    } else {
-        double z = (1.0 - x) * 0.5;
-        double s = sqrt(z);
-        double a = s + s * pm_asin_r(z);
-        return (float)(2.0 * a);
+    const double x = (double)xf;
+    const bool small = fabs(x) < 0.5, neg = x < 0.0;
+    const double z = small ? x * x : ((neg ? 1.0 + x : 1.0 - x) * 0.5);
+    const double base = small ? x : sqrt(z);
+    const double a = base + base * pm_asin_r(z);
+    const double r = small ? (PIO2_HI - a) + PIO2_LO : (neg ? PI - 2.0 * a : 2.0 * a);
+    return (fabs(x) <= 1.0) ? (float)r : __builtin_nanf("");
+}
+
+// sinf(alpha) and tanf(beta) through ONE copy of the double-precision kernels (a two-trip loop the compiler must not unroll):
+// same values as pm_sinf(alpha), pm_tanf(beta).
+MCRT_DEV void pm_sin_and_tan(float alpha, float beta, float& sin_alpha, float& tan_beta)
+{
+    sin_alpha = tan_beta = 0.0f;
+#pragma clang loop unroll(disable)
+    for (int m = 0; m < 2; ++m) {
+        const float x = m == 0 ? alpha : beta;
+        float r = pm_nan(x);
+        if (fabsf(x) <= 8192.0f) {
+            double s, c;
+            pm_sincos_d(x, s, c);
+            r = (float)s;
+            if (m == 1) r = (float)(s / c);
+        }
+        if (m == 0) sin_alpha = r; else tan_beta = r;
     }
 }
 
@@ -660,10 +674,10 @@ MCRT_DEV void pair_exact(F2 a, F2 x, F2 y, F2 z, uint32_t obj, uint32_t k, Hit& 
 }
 
 template <bool kCount>
-MCRT_DEV Hit cast_scan(CstPtr sm, CstPtr big, const SceneView& v, V3 o, V3 d, Counters& cn)
+MCRT_DEV Hit cast_scan(CstPtr sm, CstPtr big, const SceneView& v, V3 o, V3 d, Counters& cn, bool live = true)
 {
     Hit best; best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax;
-    if (kCount) cn.rays++;
+    if (kCount && live) cn.rays++;
     const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     const float tiny = 1.0e-20f;
     const bool exact_only = fabsf(d.x) < tiny || fabsf(d.y) < tiny || fabsf(d.z) < tiny;
@@ -672,9 +686,9 @@ MCRT_DEV Hit cast_scan(CstPtr sm, CstPtr big, const SceneView& v, V3 o, V3 d, Co
         const U8 head = *(const __attribute__((address_space(4))) U8*)rec;   // kind, first_tri, tri_count, first_prim, radius, pos
         if (head.s0 == MCRT_OBJECT_SPHERE) {
             // SphereObject::Intersects, source/objects/sphere.h:16-52
-            if (kCount) cn.spheres++;
+            if (kCount && live) cn.spheres++;
             const float radius = __uint_as_float(head.s4);
-            if (!(radius < kFltEpsilon)) {
+            if (live && !(radius < kFltEpsilon)) {
                 const float radiusSq = radius * radius;
                 const V3 L = mk(__uint_as_float(head.s5), __uint_as_float(head.s6), __uint_as_float(head.s7)) - o;
                 const float tca = dot(L, d);
@@ -688,8 +702,8 @@ MCRT_DEV Hit cast_scan(CstPtr sm, CstPtr big, const SceneView& v, V3 o, V3 d, Co
                 }
             }
         } else {
-            if (kCount) cn.gates++;
-            const bool pass = gate_hit_fast(rec, o, d, inv, exact_only);
+            if (kCount && live) cn.gates++;
+            const bool pass = live && gate_hit_fast(rec, o, d, inv, exact_only);
             if (__ballot(pass) == 0ull) continue;             // nobody in the wave needs this mesh
             const uint32_t count = head.s2;
             CstPtr pr = big + v.off_pair + (size_t)rec[OBJ_FIRST_PAIR] * PAIR_STRIDE;
@@ -743,9 +757,9 @@ MCRT_DEV void wave_sync()
 }
 
 template <bool kCount>
-MCRT_DEV Hit cast_flat(CstPtr sm, LdsPtr big, LdsRw area, const SceneView& v, V3 o, V3 d, Counters& cn)
+MCRT_DEV Hit cast_flat(CstPtr sm, LdsPtr big, LdsRw area, const SceneView& v, V3 o, V3 d, Counters& cn, bool live = true)
 {
-    if (kCount) cn.rays++;
+    if (kCount && live) cn.rays++;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t act = __ballot(1);
     const uint32_t nact = (uint32_t)__popcll(act);
@@ -771,9 +785,9 @@ MCRT_DEV Hit cast_flat(CstPtr sm, LdsPtr big, LdsRw area, const SceneView& v, V3
         const U8 head = *(const __attribute__((address_space(4))) U8*)rec;   // kind, first_tri, tri_count, first_prim, radius, pos
         if (head.s0 == MCRT_OBJECT_SPHERE) {
             // SphereObject::Intersects, source/objects/sphere.h:16-52
-            if (kCount) cn.spheres++;
+            if (kCount && live) cn.spheres++;
             const float radius = __uint_as_float(head.s4);
-            if (!(radius < kFltEpsilon)) {
+            if (live && !(radius < kFltEpsilon)) {
                 const float radiusSq = radius * radius;
                 const V3 L = mk(__uint_as_float(head.s5), __uint_as_float(head.s6), __uint_as_float(head.s7)) - o;
                 const float tca = dot(L, d);
@@ -788,8 +802,8 @@ MCRT_DEV Hit cast_flat(CstPtr sm, LdsPtr big, LdsRw area, const SceneView& v, V3
             }
             continue;
         }
-        if (kCount) cn.gates++;
-        const bool pass = gate_hit_fast(rec, o, d, inv, exact_only);
+        if (kCount && live) cn.gates++;
+        const bool pass = live && gate_hit_fast(rec, o, d, inv, exact_only);
         const uint64_t mask = __ballot(pass);
         if (mask == 0ull) continue;                                   // nobody in the wave needs this mesh
         const uint32_t count = head.s2, first = head.s1;
@@ -863,51 +877,73 @@ MCRT_DEV Hit cast_flat(CstPtr sm, LdsPtr big, LdsRw area, const SceneView& v, V3
 }
 
 template <int kAccel, class PS, class PB, bool kCount> struct Caster {
-    static MCRT_DEV Hit run(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters& cn)
+    static MCRT_DEV Hit run(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters& cn, bool live)
     {
+        if (!live) { Hit h; h.prim = MISS; h.obj = MISS; h.elem = 0; h.t = kFltMax; return h; }
         if (kAccel == MCRT_ACCEL_BRUTE) return cast_brute<PS, PB, kCount>(sm, big, v, o, d, cn);
         return cast_octree<PS, PB, kCount>(sm, big, v, o, d, cn);
     }
 };
 template <bool kCount> struct Caster<MCRT_ACCEL_FLAT, CstPtr, LdsPtr, kCount> {
-    static MCRT_DEV Hit run(CstPtr sm, LdsPtr big, const SceneView& v, V3 o, V3 d, Counters& cn)
+    static MCRT_DEV Hit run(CstPtr sm, LdsPtr big, const SceneView& v, V3 o, V3 d, Counters& cn, bool live)
     {
         // the per-wavefront work area follows the staged triangle records in LDS
         LdsRw area = (LdsRw)(big + ((v.ntri * TRI_STRIDE + 3u) & ~3u)) + (threadIdx.x >> 6) * FLAT_AREA_WORDS;
-        return cast_flat<kCount>(sm, big, area, v, o, d, cn);
+        return cast_flat<kCount>(sm, big, area, v, o, d, cn, live);
     }
 };
 template <bool kCount> struct Caster<MCRT_ACCEL_SCAN, CstPtr, CstPtr, kCount> {
-    static MCRT_DEV Hit run(CstPtr sm, CstPtr big, const SceneView& v, V3 o, V3 d, Counters& cn) { return cast_scan<kCount>(sm, big, v, o, d, cn); }
+    static MCRT_DEV Hit run(CstPtr sm, CstPtr big, const SceneView& v, V3 o, V3 d, Counters& cn, bool live) { return cast_scan<kCount>(sm, big, v, o, d, cn, live); }
 };
 
 template <int kAccel, class PS, class PB, bool kCount>
-MCRT_DEV Hit cast(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters& cn)
+MCRT_DEV Hit cast(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters& cn, bool live = true)
 {
-    return Caster<kAccel, PS, PB, kCount>::run(sm, big, v, o, d, cn);
+    // live == false: the lane takes part in the wavefront's cooperative work but has no ray of its own (answer: a miss)
+    return Caster<kAccel, PS, PB, kCount>::run(sm, big, v, o, d, cn, live);
 }
 // --------------------------------------------------------------- materials
-// Material::BRDF, source/core/material.h:24-53
-template <class PS> MCRT_DEV double brdf(PS sm, uint32_t orec, V3 incident, V3 reflection, V3 normal)
+// Material::BRDF, source/core/material.h:24-53, for the (up to) two outgoing directions one diffuse hit needs - r0 towards the
+// light sample (scene.cpp:137), r1 the hemisphere bounce (scene.cpp:164) - in one place.  The Oren-Nayar branch is by far the
+// most expensive piece of shading (three acosf, sinf, tanf per direction pair, all through double-precision kernels), only a
+// few lanes of a wavefront need it at a time, and a wavefront executes every copy of it that ANY lane needs: so it exists once.
+// The three acosf run through one copy of the kernel (trip 0: theta_in, shared by both directions), the two directions through
+// one copy of the sin/tan part.  A and B depend on the roughness alone (material.h:29-33) and come precomputed with the object
+// record (same float operations, done once at upload).  Values are those of the reference's expression, operation by operation.
+template <class PS>
+MCRT_DEV void brdf2(PS sm, uint32_t orec, V3 incident, V3 normal, bool want0, V3 r0, bool want1, V3 r1, double& f0, double& f1)
 {
-    float albedo = ldf(sm, orec + OBJ_ALBEDO);
+    const float albedo = ldf(sm, orec + OBJ_ALBEDO);
+    f0 = f1 = (double)albedo;
     if (sm[orec + OBJ_DIFFUSE] == MCRT_DIFFUSE_OREN_NAYAR) {
-        float roughness = ldf(sm, orec + OBJ_ROUGHNESS);
-        float sigma2 = roughness * roughness;
-        float A = 1.0f - 0.5f * sigma2 / (sigma2 + 0.57f);
-        float B = 0.45f * sigma2 / (sigma2 + 0.09f);
-        float cos_in = dot(incident, normal);
-        float cos_out = dot(reflection, normal);
-        float cos_in_out = dot(incident, reflection);
-        float theta_in = pm_acosf(cos_in);
-        float theta_out = pm_acosf(cos_out);
-        float alpha = (theta_out < theta_in) ? theta_in : theta_out;
-        float beta = (theta_in < theta_out) ? theta_in : theta_out;
-        float mx = (0.0f < cos_in_out) ? cos_in_out : 0.0f;
-        double ON = (double)(A + (B * mx) * pm_sinf(alpha) * pm_tanf(beta));
-        return (double)albedo * ON;
+        const float A = ldf(sm, orec + OBJ_ON_A), B = ldf(sm, orec + OBJ_ON_B);
+        const float cos_in = dot(incident, normal);
+        const float cos_out0 = dot(r0, normal), cos_out1 = dot(r1, normal);
+        const float cio0 = dot(incident, r0), cio1 = dot(incident, r1);
+        float theta_in = 0.0f, theta_out0 = 0.0f, theta_out1 = 0.0f;
+#pragma clang loop unroll(disable)
+        for (int j = 0; j < 3; ++j) {
+            if (j == 0 || (j == 1 && want0) || (j == 2 && want1)) {
+                const float t = pm_acosf(j == 0 ? cos_in : (j == 1 ? cos_out0 : cos_out1));
+                if (j == 0) theta_in = t; else if (j == 1) theta_out0 = t; else theta_out1 = t;
+            }
+        }
+#pragma clang loop unroll(disable)
+        for (int j = 0; j < 2; ++j) {
+            if (j == 0 ? want0 : want1) {
+                const float theta_out = j == 0 ? theta_out0 : theta_out1;
+                const float cos_in_out = j == 0 ? cio0 : cio1;
+                const float alpha = (theta_out < theta_in) ? theta_in : theta_out;       // std::max(theta_out, theta_in)
+                const float beta = (theta_in < theta_out) ? theta_in : theta_out;        // std::min(theta_out, theta_in)
+                const float mx = (0.0f < cos_in_out) ? cos_in_out : 0.0f;                 // std::max(0.0f, cos_in_out)
+                float sin_alpha, tan_beta;
+                pm_sin_and_tan(alpha, beta, sin_alpha, tan_beta);
+                const double ON = (double)(A + (B * mx) * sin_alpha * tan_beta);
+                const double f = (double)albedo * ON;
+                if (j == 0) f0 = f; else f1 = f;
+            }
+        }
     }
-    return (double)albedo;
 }
 
 // Scene::RandomHemisphereRay, source/scene.cpp:11-30
@@ -952,6 +988,13 @@ template <class PS> MCRT_DEV V3 light_point(PS sm, uint32_t orec, Rng& g)
         return mk(pos.x + (radius * sphi * cth), pos.y + (radius * sphi * sth), pos.z + (radius * cphi));
     }
     return pos;
+}
+
+// Advance the generator past the draws light_point makes for this light, without sampling it.
+template <class PS> MCRT_DEV void light_skip(PS sm, uint32_t orec, Rng& g)
+{
+    const uint32_t kind = sm[orec + OBJ_KIND];
+    if (kind == MCRT_OBJECT_LIGHT || kind == MCRT_OBJECT_SPHERE) { (void)rng_next(g); (void)rng_next(g); }
 }
 
 // Object::GetSurfaceNormal: sphere.h:54-57 / mesh.cpp:43-46

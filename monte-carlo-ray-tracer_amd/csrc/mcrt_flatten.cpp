@@ -405,6 +405,15 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
         w[OBJ_ALBEDO] = fbits(o.material.albedo);
         w[OBJ_ROUGHNESS] = fbits(o.material.roughness);
         w[OBJ_IOR] = fbits(o.material.refractive_index);
+        {
+            // Material::BRDF, source/core/material.h:29-33 (float arithmetic, one rounding per operation)
+            volatile float sigma2 = o.material.roughness * o.material.roughness;
+            volatile float qa = 0.5f * sigma2 / (sigma2 + 0.57f);
+            volatile float qb = 0.45f * sigma2 / (sigma2 + 0.09f);
+            volatile float A = 1.0f - qa;
+            w[OBJ_ON_A] = fbits(A);
+            w[OBJ_ON_B] = fbits(qb);
+        }
         for (int a = 0; a < 3; ++a) {
             put_double(out.small_img, v.off_obj + size_t(i) * OBJ_STRIDE + OBJ_COLOR + 2 * a, o.material.color[a]);
             put_double(out.small_img, v.off_obj + size_t(i) * OBJ_STRIDE + OBJ_EMISSION + 2 * a, o.material.emission[a]);

@@ -38,6 +38,8 @@ enum : uint32_t {
     OBJ_FIRST_PAIR = 25, // index of this mesh's first triangle-pair record (scan path)
     OBJ_COLOR = 26,      // 3 doubles (8-byte aligned: stride and offset are even)
     OBJ_EMISSION = 32,   // 3 doubles
+    OBJ_ON_A = 38,       // Oren-Nayar A and B of source/core/material.h:29-33: functions of the roughness alone,
+    OBJ_ON_B = 39,       // evaluated once at upload with the reference's float operations
     OBJ_STRIDE = 40
 };
 
