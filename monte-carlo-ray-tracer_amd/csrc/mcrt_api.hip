@@ -151,6 +151,13 @@ template <> struct WalkStackFor<GlbPtr> {
 constexpr uint32_t kWalkLdsWords = LDS_STACK_ENTRIES * 3 * LDS_STACK_BLOCK;
 static_assert(LDS_STACK_BLOCK == kBlock, "LdsStack columns are one per thread of the block");
 
+// Scheduling knobs of trace_lane (wave-uniform runtime values, so that they can be swept without rebuilding):
+//   min_trace   lanes with a camera / bounce ray are served when at least this many are waiting (0: always)
+//   fetch_min   idle lanes fetch their next items together once this many are idle (1: at once)
+//   refill      octree walk: bits 0..7: hand back control once fewer than refill/64 of the lanes that entered are still walking
+//               (0: walk to the end); bits 8..: leaf records per visit (OctreeWalk::visit)
+struct LanePolicy { uint32_t min_trace, fetch_min, refill; };
+
 enum : uint32_t { ST_NEW = 0, ST_TRACE = 1, ST_SHADOW = 2, ST_DONE = 3, ST_FETCH = 4 };
 
 // Explicit start of a TraceRay call (mcrt_trace_rays): ray, generator state and importance come from
@@ -180,7 +187,7 @@ struct ExplicitStart {
 template <class PS, class PB, int kAccel, bool kCount, bool kMulti, class Work>
 __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, const CameraDev& cam, uint64_t seed, uint32_t max_depth,
                                            const PendStack& pend, bool keep_nonfinite, Counters& cn, RenderCounters& rc, Work& work,
-                                           uint32_t refill, uint32_t* walk_lds)
+                                           const LanePolicy policy, uint32_t* walk_lds)
 {
     D3 sum = dmk(0.0, 0.0, 0.0);
     uint32_t dropped = 0;
@@ -208,6 +215,10 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
     uint32_t horec = 0;
     Rng g_l; g_l.s0 = 0; g_l.s1 = 0;
 
+    // Fetch policy: idle lanes wait until fetch_min of them can fetch together (or nobody is left working); they then receive
+    // consecutive items - neighbouring pixels of one tile - which keeps the wavefront's rays coherent (the wave-uniform scan
+    // culls whole meshes per wavefront).  fetch_min == 64 is a round: everybody waits for the slowest lane.
+    const uint32_t kMinTrace = policy.min_trace, kFetchMin = policy.fetch_min;
     // Octree path: the nearest-hit query is resumable (OctreeWalk): lanes whose ray is finished are shaded
     // and given their next ray while the others stay in mid-traversal.
     constexpr bool kWalk = (kAccel == MCRT_ACCEL_OCTREE);
@@ -217,30 +228,27 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
     WalkStackFor<PB>::bind(walk_stack, walk_lds);
     bool walking = false;
     if (kWalk) walk.idle();
-#ifndef MCRT_MIN_TRACE
-#define MCRT_MIN_TRACE 36
-#endif
-    constexpr uint32_t kMinTrace = kWalk ? 0u : (uint32_t)MCRT_MIN_TRACE;
-    // Fetch policy.  kFetchMin == 1: a lane takes its next item the moment it runs dry (octree walks: long, incoherent queries).
-    // Otherwise idle lanes wait until kFetchMin of them can fetch together (or nobody is left working): they then receive
-    // consecutive items - neighbouring pixels of one tile - which keeps the wavefront's rays coherent (the wave-uniform scan
-    // culls whole meshes per wavefront) without making everybody wait for the slowest lane of a 64-item round (kFetchMin == 64).
-    constexpr uint32_t kFetchMin = kWalk ? 1u : Work::kFetchMin;
 
-    while (state != ST_DONE) {
+    // The loop is wave-uniform: a lane that has nothing left stays in it as a helper (the cooperative queries need all 64 lanes).
+    for (;;) {
+        const uint64_t busy = __ballot(state != ST_DONE);
+        if (busy == 0ull) break;
         bool fetch_ok = true;
         if (kFetchMin > 1u) {
-            const uint64_t in_loop = __ballot(1), want = __ballot(state == ST_FETCH);
-            fetch_ok = (uint32_t)__popcll(want) >= kFetchMin || want == in_loop;
+            const uint64_t want = __ballot(state == ST_FETCH);
+            fetch_ok = (uint32_t)__popcll(want) >= kFetchMin || want == busy;
         }
         if (state == ST_FETCH && fetch_ok) {
-            if (!work.next(pixel, s_begin, s_count)) { state = ST_DONE; continue; }
-            ex = work.explicit_start(exs) ? &exs : nullptr;
-            px = pixel % cam.width; py = pixel / cam.width;
-            k = 0; sum = dmk(0.0, 0.0, 0.0); dropped = 0;
-            state = ST_NEW;
+            // (no `continue` on this path: every lane has to arrive at the cooperative query below)
+            if (!work.next(pixel, s_begin, s_count)) state = ST_DONE;
+            else {
+                ex = work.explicit_start(exs) ? &exs : nullptr;
+                px = pixel % cam.width; py = pixel / cam.width;
+                k = 0; sum = dmk(0.0, 0.0, 0.0); dropped = 0;
+                state = ST_NEW;
+            }
         }
-        if (state == ST_NEW && !walking) {
+        if (state == ST_NEW) {
             // one iteration of the spp loop, source/main.cpp:122-139
             imp = dmk(1.0, 1.0, 1.0);
             if (ex) {
@@ -264,13 +272,7 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
         }
 
         Hit hit;
-        if constexpr (kWalk) {
-            if (!walking) { walk.begin(big, v, walk_stack, cn); walking = true; }
-            walk.run(sm, big, v, walk_stack, ro, rd, cn, refill & 0xFFu, refill >> 8);
-            if (!walk.done()) continue;                    // still in mid-traversal: nothing to shade yet
-            walking = false;
-            hit = walk.best;
-        } else {
+        {
             // Batching of the shading: a lane with a shadow ray is always served (what follows its query is one comparison and a
             // multiply-add); lanes with a camera / bounce ray are served when at least kMinTrace of them are waiting (or nobody has
             // a shadow ray), otherwise they sit this query out - after it every shadow lane has turned into a trace lane, so the
@@ -278,14 +280,23 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
             // for that about every other iteration, with most of its lanes in it, instead of every iteration for a minority.
             // Break-even by the instruction counts (cast ~2050, shading ~1200 per wavefront): wait when fewer than ~3/8 of the lanes are ready;
             // measured optimum of the threshold over configs 1, 2, 3 and 5: 36 (sweep 0 / 12 / 24 / 36 / 64, profiles/r02_sweep_min_trace.txt).
-            bool live = state != ST_FETCH;          // a lane waiting for an item has no ray
-            if (kMinTrace > 0 && live) {
+            bool live = state != ST_FETCH && state != ST_DONE;          // a lane waiting for an item, or finished, has no ray
+            if (kMinTrace > 0u && live) {
                 const bool is_s = state == ST_SHADOW;
                 const uint32_t n_s = (uint32_t)__popcll(__ballot(is_s)), n_t = (uint32_t)__popcll(__ballot(!is_s));
                 live = is_s || n_t >= kMinTrace || n_s == 0u;
             }
-            hit = cast<kAccel, PS, PB, kCount>(sm, big, v, ro, rd, cn, live);
-            if (!live) continue;
+            if constexpr (kWalk) {
+                // a lane without a ray has an empty stack: it sits in the walk loop as a finished lane
+                if (live && !walking) { walk.begin(big, v, walk_stack, cn); walking = true; }
+                walk.run(sm, big, v, walk_stack, ro, rd, cn, policy.refill & 0xFFu, policy.refill >> 8);
+                if (!live || !walk.done()) continue;          // no ray, or still in mid-traversal: nothing to shade yet
+                walking = false;
+                hit = walk.best;
+            } else {
+                hit = cast<kAccel, PS, PB, kCount>(sm, big, v, ro, rd, cn, live);
+                if (!live) continue;
+            }
         }
 
         bool branch_done = false;      // this TraceRay chain returned; continue with a parked branch or finish the sample
@@ -455,7 +466,7 @@ struct RenderArgs {
     uint32_t wave_slices_log2;  // slices of one pixel that share a wavefront
     uint32_t slices;            // sample slices per pixel (mcrt_lanes_per_pixel)
     uint32_t items;             // tiles * 64 * slices
-    uint32_t refill;            // octree walk: leave the walk loop below refill/64 of the lanes that entered (0: never)
+    LanePolicy policy;
     uint64_t seed;
 };
 
@@ -480,8 +491,7 @@ __device__ __forceinline__ void flush_counters(unsigned long long* out, const Co
 //
 // Lanes that run dry fetch together (trace_lane waits until kFetchMin of them can, Work::kFetchMin): one atomic per
 // wavefront and fetch, consecutive items - pixels of one tile - for the lanes that take part.
-template <uint32_t kFetchMinT> struct RenderWork {
-    static constexpr uint32_t kFetchMin = kFetchMinT;
+struct RenderWork {
     const RenderArgs& a;
     uint32_t slice;
     uint32_t dropped_total;
@@ -547,13 +557,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_render(const RenderArgs a)
     pend.lane = blockIdx.x * blockDim.x + threadIdx.x;
     Counters cn = { 0, 0, 0, 0, 0 };
     RenderCounters rc = { 0, 0, 0 };
-#ifndef MCRT_FETCH_MIN
-#define MCRT_FETCH_MIN 64
-#endif
-    // scan / flat / LDS-resident variants keep their lanes on few tiles (coherent rays); walks through an HBM-resident octree run free
-    constexpr uint32_t kFetchMin = (kBigLds || kAccel == MCRT_ACCEL_SCAN || kAccel == MCRT_ACCEL_FLAT) ? (uint32_t)MCRT_FETCH_MIN : 1u;
-    RenderWork<kFetchMin> work = { a, 0u, 0u };
-    trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount, kMulti>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, false, cn, rc, work, a.refill, walk_lds);
+    RenderWork work = { a, 0u, 0u };
+    trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount, kMulti>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, false, cn, rc, work, a.policy, walk_lds);
     if (work.dropped_total) atomicAdd(a.tile_counter + 1, work.dropped_total);
     if (kCount) flush_counters(a.counters, cn, rc);
 }
@@ -590,7 +595,6 @@ struct ListArgs {
 
 // Work items of mcrt_trace_samples / mcrt_trace_rays: entry i of the caller's arrays, grid-strided per lane.
 struct ListWork {
-    static constexpr uint32_t kFetchMin = 1;
     const ListArgs& a;
     uint64_t i, stride, cur;
     __device__ __forceinline__ bool next(uint32_t& pixel, uint32_t& s_begin, uint32_t& s_count)
@@ -631,7 +635,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_list(const ListArgs a)
     Counters cn = { 0, 0, 0, 0, 0 };
     RenderCounters rc = { 0, 0, 0 };
     ListWork work = { a, pend.lane, (uint64_t)gridDim.x * blockDim.x, 0 };
-    trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount, kMulti>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, true, cn, rc, work, a.refill, walk_lds);
+    const LanePolicy policy = { 0u, 1u, a.refill };
+    trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount, kMulti>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, true, cn, rc, work, policy, walk_lds);
     if (kCount) flush_counters(a.counters, cn, rc);
 }
 
@@ -647,14 +652,20 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const SceneView v, uint64_
     Mem::open(v, smem, sm, big);
     Counters cn = { 0, 0, 0, 0, 0 };
     RenderCounters rc = { 0, 0, 0 };
+    // every wavefront runs the same number of trips with all 64 lanes (the cooperative queries need them): lanes past the end help
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const V3 ro = mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
-        const V3 rd = mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-        const Hit h = cast<kAccel, typename Mem::PS, typename Mem::PB, kCount>(sm, big, v, ro, rd, cn);
-        out_obj[i] = (h.obj == MISS) ? -1 : (int32_t)h.obj;
-        out_elem[i] = h.elem;
-        out_t[i] = h.t;
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < n; base += stride) {
+        const uint64_t i = base + (threadIdx.x & 63u);
+        const bool live = i < n;
+        const uint64_t k = live ? i : 0;
+        const V3 ro = mk(o[3 * k], o[3 * k + 1], o[3 * k + 2]);
+        const V3 rd = mk(d[3 * k], d[3 * k + 1], d[3 * k + 2]);
+        const Hit h = cast<kAccel, typename Mem::PS, typename Mem::PB, kCount>(sm, big, v, ro, rd, cn, live);
+        if (live) {
+            out_obj[i] = (h.obj == MISS) ? -1 : (int32_t)h.obj;
+            out_elem[i] = h.elem;
+            out_t[i] = h.t;
+        }
     }
     if (kCount) flush_counters(counters, cn, rc);
 }
@@ -682,14 +693,19 @@ __global__ __launch_bounds__(kBlock) void k_unlit(const SceneView v, const Camer
     Counters cn = { 0, 0, 0, 0, 0 };
     const uint64_t npix = (uint64_t)cam.width * cam.height;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
-        const uint32_t x = (uint32_t)(i % cam.width), y = (uint32_t)(i / cam.width);
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < npix; base += stride) {
+        const uint64_t i = base + (threadIdx.x & 63u);
+        const bool live = i < npix;
+        const uint64_t k = live ? i : 0;
+        const uint32_t x = (uint32_t)(k % cam.width), y = (uint32_t)(k / cam.width);
         V3 o, d;
         camera_ray(cam, (float)x + 0.5f, (float)y + 0.5f, o, d);     // source/main.cpp:126
-        const Hit h = cast<kAccel, typename Mem::PS, typename Mem::PB, false>(sm, big, v, o, d, cn);
-        D3 c = dmk(0.0, 0.0, 0.0);
-        if (h.obj != MISS) c = ldd3(sm, v.off_obj + h.obj * OBJ_STRIDE + OBJ_COLOR);
-        out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+        const Hit h = cast<kAccel, typename Mem::PS, typename Mem::PB, false>(sm, big, v, o, d, cn, live);
+        if (live) {
+            D3 c = dmk(0.0, 0.0, 0.0);
+            if (h.obj != MISS) c = ldd3(sm, v.off_obj + h.obj * OBJ_STRIDE + OBJ_COLOR);
+            out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+        }
     }
 }
 
@@ -774,9 +790,11 @@ struct mcrt_ctx {
     size_t resolve_img_pixels = 0, resolve_mean_pixels = 0;
     double* d_partial = nullptr;                // slice sums of the current pass, [slices][pixels][3]
     size_t partial_bytes = 0;
-    int chunk_override = 0;                     // MCRT_LEAF_CHUNK (tuning knob)
+    int min_trace_override = -1;                // MCRT_MIN_TRACE (tuning knob): LanePolicy::min_trace
+    int fetch_min_override = -1;                // MCRT_FETCH_MIN (tuning knob): LanePolicy::fetch_min
+    int refill_override = -1;                   // MCRT_REFILL (tuning knob): LanePolicy::refill, threshold
+    int chunk_override = 0;                     // MCRT_LEAF_CHUNK (tuning knob): LanePolicy::refill, leaf records per visit
     uint32_t wave_slices = 64;                  // MCRT_WAVE_SLICES (tuning knob): slices of a pixel that share a wavefront, at most
-    int refill_override = -1;                   // MCRT_REFILL (tuning knob): see RenderArgs::refill
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -875,7 +893,7 @@ int launch_intersect_t(mcrt_ctx* c, uint64_t n, const float* o, const float* d, 
     auto kern = k_intersect<kBigLds, kAccel, kCount>;
     int rc = set_lds_limit(c, kern, lds_for(c));
     if (rc) return rc;
-    uint32_t blocks = (uint32_t)std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)grid_for(c) * 4);
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)grid_for(c));
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(kBlock), lds_for(c), c->stream, view_for(c), n, o, d, obj, elem, t, c->d_counters);
     HIP_TRY(c, hipGetLastError());
@@ -925,14 +943,22 @@ int launch_unlit(mcrt_ctx* c, double* out)
     return c->big_in_lds ? launch_unlit_t<true, MCRT_ACCEL_OCTREE>(c, out) : launch_unlit_t<false, MCRT_ACCEL_OCTREE>(c, out);
 }
 
-// measured (profiles/r01_refill_sweep.txt): refilling pays when the image is walked from HBM/L2 (long,
-// exponentially distributed walks); with an LDS-resident image the extra shading passes cost more than they save
-// bits 0..7: refill threshold; bits 8..: leaf records per visit (OctreeWalk::visit)
-uint32_t walk_refill(const mcrt_ctx* c)
+// Scheduling of the render kernel's lanes (LanePolicy), measured per kernel family:
+//   scan / flat / LDS-resident scenes: trace lanes batched from 36 up (profiles/r02_sweep_min_trace.txt), fetches in rounds of 64
+//   (smaller fetch groups mix tiles in a wavefront and lose 8 % and more, profiles/r02_sweep_fetch_min.txt);
+//   octree over an HBM-resident image: lanes run free (fetch at once, no batching): walks are long and incoherent anyway.
+LanePolicy lane_policy(const mcrt_ctx* c)
 {
+    const bool walk_hbm = c->accel == MCRT_ACCEL_OCTREE && !c->big_in_lds;
+    LanePolicy p;
+    p.min_trace = c->min_trace_override >= 0 ? (uint32_t)c->min_trace_override : (walk_hbm ? 0u : 36u);
+    p.fetch_min = c->fetch_min_override >= 1 ? (uint32_t)c->fetch_min_override : (walk_hbm ? 1u : 64u);
+    // measured (profiles/r01_refill_sweep.txt): refilling pays when the image is walked from HBM/L2 (long, exponentially distributed
+    // walks); with an LDS-resident image the extra shading passes cost more than they save
     const uint32_t refill = c->refill_override >= 0 ? (uint32_t)c->refill_override : (c->big_in_lds ? 0u : 40u);
     const uint32_t chunk = c->chunk_override > 0 ? (uint32_t)c->chunk_override : (c->big_in_lds ? 0xFFFFFFu : 4u);
-    return refill | (chunk << 8);
+    p.refill = refill | (chunk << 8);
+    return p;
 }
 
 int need_scene(mcrt_ctx* c, bool camera)
@@ -973,9 +999,11 @@ int mcrt_create(int device_id, mcrt_ctx** out_ctx)
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* e = getenv("MCRT_MIN_TRACE")) { int r = atoi(e); if (r >= 0 && r <= 64) c->min_trace_override = r; }
     if (const char* e = getenv("MCRT_REFILL")) { int r = atoi(e); if (r >= 0 && r <= 64) c->refill_override = r; }
-    if (const char* e = getenv("MCRT_WAVE_SLICES")) { int r = atoi(e); if (r >= 1 && r <= 64) c->wave_slices = (uint32_t)r; }
     if (const char* e = getenv("MCRT_LEAF_CHUNK")) { int r = atoi(e); if (r > 0 && r < (1 << 20)) c->chunk_override = r; }
+    if (const char* e = getenv("MCRT_FETCH_MIN")) { int r = atoi(e); if (r >= 1 && r <= 64) c->fetch_min_override = r; }
+    if (const char* e = getenv("MCRT_WAVE_SLICES")) { int r = atoi(e); if (r >= 1 && r <= 64) c->wave_slices = (uint32_t)r; }
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     c->stream = c->own_stream;
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
@@ -1206,7 +1234,7 @@ int mcrt_trace_samples(mcrt_ctx* c, uint64_t n, const uint32_t* pixels, const ui
     a.view = view_for(c); a.cam = c->cam; a.pixels = dp.p; a.samples = ds.p; a.out = dout.p; a.counters = c->d_counters; a.pend = c->d_pend;
     a.n = n; a.max_depth = max_depth; a.seed = seed;
     a.ray_o = nullptr; a.ray_d = nullptr; a.ray_state = nullptr; a.ray_importance = nullptr;
-    a.refill = walk_refill(c);
+    a.refill = lane_policy(c).refill;
     rc = launch_list(c, a);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(out, dout.p, n * 24, hipMemcpyDeviceToHost, c->stream));
@@ -1241,7 +1269,7 @@ int mcrt_trace_rays(mcrt_ctx* c, uint64_t n, const float* origins, const float* 
     a.view = view_for(c); a.cam = c->cam; a.pixels = nullptr; a.samples = nullptr; a.out = dout.p; a.counters = c->d_counters; a.pend = c->d_pend;
     a.n = n; a.max_depth = max_depth; a.seed = 0;
     a.ray_o = dor.p; a.ray_d = ddi.p; a.ray_state = dst.p; a.ray_importance = dimp.p;
-    a.refill = walk_refill(c);
+    a.refill = lane_policy(c).refill;
     rc = launch_list(c, a);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(out, dout.p, n * 24, hipMemcpyDeviceToHost, c->stream));
@@ -1311,7 +1339,7 @@ int mcrt_render(mcrt_ctx* c, uint32_t sample_begin, uint32_t sample_count, uint3
     RenderArgs a;
     a.view = view_for(c); a.cam = c->cam; a.accum = c->d_accum; a.tile_counter = c->d_tile; a.counters = c->d_counters; a.pend = c->d_pend;
     a.s_begin = sample_begin; a.s_count = sample_count; a.max_depth = max_depth;
-    a.refill = walk_refill(c);
+    a.policy = lane_policy(c);
     a.slices = c->lanes_override ? std::min<uint32_t>(c->lanes_override, sample_count) : mcrt_lanes_per_pixel(c->cam.width, c->cam.height, sample_count);
     {
         // the slices of a pixel share a wavefront (4 slices: 4x4 pixels x 4 slices): a smaller pixel footprint per

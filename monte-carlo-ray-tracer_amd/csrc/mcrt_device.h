@@ -356,6 +356,14 @@ MCRT_DEV Hit cast_brute(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters&
     return best;
 }
 
+typedef __attribute__((address_space(3))) uint32_t* LdsRw;
+
+MCRT_DEV void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Nearest hit through the flat octree.  Same result as cast_brute: the
 // candidate set is every primitive whose mesh gate passes, the winner is the
 // lexicographic minimum of (t, primitive id) - "earlier object / earlier
@@ -748,14 +756,6 @@ constexpr uint32_t FLAT_ELEM_BITS = 20;
 #define MCRT_FLAT_MIN 24
 #endif
 constexpr uint32_t FLAT_MIN_SCAN_LANES = MCRT_FLAT_MIN;
-typedef __attribute__((address_space(3))) uint32_t* LdsRw;
-
-MCRT_DEV void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
 template <bool kCount>
 MCRT_DEV Hit cast_flat(CstPtr sm, LdsPtr big, LdsRw area, const SceneView& v, V3 o, V3 d, Counters& cn, bool live = true)
 {
