@@ -161,7 +161,11 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* scene,
                       const mcrt_accel_params* accel);
 
 /* Camera::Camera + Camera::SetView, source/core/camera.h:19-34; also sizes
- * the PixelBuffer accumulators (source/core/pixelbuffer.cpp:7-23). */
+ * and zeroes the PixelBuffer accumulators (source/core/pixelbuffer.cpp:7-23):
+ * the accumulator in use is cleared, a caller-bound one included.  When the
+ * image SIZE changes, a buffer bound with mcrt_bind_accumulator no longer fits:
+ * the context returns to its own accumulator and the caller binds a buffer of
+ * the new size again (mcrt_accumulator tells which one is in use). */
 int mcrt_set_camera(mcrt_ctx* ctx, const mcrt_camera* camera);
 
 /* Host-only helper: fill an mcrt_camera the way the reference does -
@@ -242,6 +246,14 @@ void mcrt_rng_seed(uint64_t seed, uint32_t pixel, uint32_t sample, uint64_t out_
  * source/core/pixelbuffer.cpp:14-18. */
 int mcrt_clear(mcrt_ctx* ctx);
 
+/* Samples dropped because a component was not finite (stated deviation, see
+ * mcrt_render) since the last mcrt_clear / mcrt_set_camera, over all passes.
+ * The reference would have added them and poisoned the pixel for good
+ * (source/core/pixelbuffer.cpp:39-46); mcrt_resolve still divides by the
+ * spp_total it is given, as the reference divides by its ray count.
+ * Synchronises the context's stream. */
+int mcrt_dropped_samples(mcrt_ctx* ctx, uint64_t* out_count);
+
 /* Use caller-owned device memory (width*height*3 doubles) as the radiance
  * accumulator, so the caller can all-reduce it (RCCL) between passes.
  * NULL returns to the context's own buffer.  No reference counterpart. */
@@ -249,6 +261,32 @@ int mcrt_bind_accumulator(mcrt_ctx* ctx, double* d_accum);
 
 /* Device address of the accumulator currently in use. */
 int mcrt_accumulator(mcrt_ctx* ctx, double** out_d_accum);
+
+/* ---- multi-GPU: the reduce() of the drop-in boundary.
+ * The reference runs one worker thread per hardware thread over shared
+ * accumulators (source/main.cpp:59-62,250-262).  Here every GPU has its own
+ * context and accumulator and renders its own share of the sample indices;
+ * between passes the accumulators are summed into one rank's, which resolves.
+ *
+ * mcrt_reduce: ncclReduce(sum, ncclDouble, width*height*3) of the accumulator
+ * in use into rank `root`, in place, on the context's stream (asynchronous).
+ * `comm` is an ncclComm_t (RCCL); every rank of the communicator calls it, each
+ * from its own thread or process.  RCCL is bound at run time: without librccl
+ * the call fails with MCRT_ERR_NO_DEVICE and nothing else is affected.
+ * mcrt_comm_init_all / mcrt_comm_destroy: ncclCommInitAll / ncclCommDestroy for
+ * the one-process-many-GPUs case (out_comms: n ncclComm_t, rank i on
+ * devices[i]), so that a C caller needs no RCCL headers.  A process that
+ * already has communicators (MPI / torch.distributed launchers) passes its
+ * own ncclComm_t to mcrt_reduce.
+ * mcrt_add_accumulator: accumulator += d_src (width*height*3 doubles in
+ * memory this GPU can read: another context of the same GPU, or a peer
+ * buffer) - the reduction step where no communicator exists, e.g. several
+ * contexts on one GPU.  Runs on this context's stream; the caller orders it
+ * after the producer of d_src (mcrt_synchronize on that context). */
+int mcrt_reduce(mcrt_ctx* ctx, void* nccl_comm, int root);
+int mcrt_comm_init_all(int n, const int* devices, void** out_comms);
+int mcrt_comm_destroy(void* nccl_comm);
+int mcrt_add_accumulator(mcrt_ctx* ctx, const double* d_src);
 
 /* The hot loop: TracePixels/RayTraceNextPixel, source/main.cpp:100-184, for
  * every pixel and for samples [sample_begin, sample_begin+sample_count):

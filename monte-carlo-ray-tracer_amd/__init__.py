@@ -22,9 +22,9 @@ LIB_PATH = os.path.join(HERE, "libmcrt_hip.so")
 ABI_SYMBOLS = (
     "mcrt_create", "mcrt_destroy", "mcrt_last_error", "mcrt_set_stream", "mcrt_upload_scene", "mcrt_set_camera", "mcrt_set_accel",
     "mcrt_camera_rays", "mcrt_intersect", "mcrt_intersect_device", "mcrt_intersect_noalloc", "mcrt_trace_samples", "mcrt_trace_rays", "mcrt_render_unlit", "mcrt_rng_seed",
-    "mcrt_clear", "mcrt_bind_accumulator", "mcrt_accumulator", "mcrt_render", "mcrt_last_render_ms", "mcrt_resolve",
+    "mcrt_clear", "mcrt_dropped_samples", "mcrt_bind_accumulator", "mcrt_accumulator", "mcrt_render", "mcrt_last_render_ms", "mcrt_resolve",
     "mcrt_read_accumulator", "mcrt_write_accumulator", "mcrt_synchronize", "mcrt_octree_info_get", "mcrt_octree_download", "mcrt_set_counting", "mcrt_counters",
-    "mcrt_lanes_per_pixel", "mcrt_set_lanes_per_pixel",
+    "mcrt_lanes_per_pixel", "mcrt_set_lanes_per_pixel", "mcrt_reduce", "mcrt_comm_init_all", "mcrt_comm_destroy", "mcrt_add_accumulator",
     "mcrt_camera_look_at", "mcrt_scene_image_create", "mcrt_scene_image_destroy", "mcrt_scene_image_info", "mcrt_scene_image_octree",
 )
 
@@ -102,6 +102,21 @@ def build_scene_image(flat, accel=None):
     finally:
         lib.mcrt_scene_image_destroy(img)
     return info, box, words, refs
+
+
+def comm_init_all(devices):
+    """ncclCommInitAll through the library (mcrt_comm_init_all): one communicator handle per listed device."""
+    lib = load_library()
+    n = len(devices)
+    comms = (C.c_void_p * n)()
+    rc = lib.mcrt_comm_init_all(C.c_int(n), (C.c_int * n)(*devices), comms)
+    if rc:
+        raise McrtError(rc, (lib.mcrt_last_error(None) or b"").decode())
+    return [c for c in comms]
+
+
+def comm_destroy(comm):
+    load_library().mcrt_comm_destroy(C.c_void_p(comm))
 
 
 COUNTER_NAMES = ("rays", "nodes", "tris", "spheres", "gates", "samples", "trace_calls", "splits")
@@ -221,8 +236,19 @@ class Backend:
     def clear(self):
         self._ck(self.lib.mcrt_clear(self.ctx))
 
+    def dropped_samples(self):
+        n = C.c_uint64()
+        self._ck(self.lib.mcrt_dropped_samples(self.ctx, C.byref(n)))
+        return int(n.value)
+
     def bind_accumulator(self, device_address):
         self._ck(self.lib.mcrt_bind_accumulator(self.ctx, C.c_void_p(device_address)))
+
+    def add_accumulator(self, device_address):
+        self._ck(self.lib.mcrt_add_accumulator(self.ctx, C.c_void_p(device_address)))
+
+    def reduce(self, comm, root=0):
+        self._ck(self.lib.mcrt_reduce(self.ctx, C.c_void_p(comm), C.c_int(root)))
 
     def accumulator_address(self):
         p = C.c_void_p()

@@ -18,6 +18,7 @@
 //   k_resolve       mean / tonemap / gamma / BGRA8 (source/main.cpp:142-164,
 //                   source/opengl/data.cpp:28-55).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -458,7 +459,8 @@ struct RenderArgs {
     CameraDev cam;
     double* accum;
     double* partial;            // [slices][pixels][3] when slices > 1
-    uint32_t* tile_counter;     // [0] next work item, [1] dropped samples
+    uint32_t* tile_counter;     // [0] next work item
+    unsigned long long* dropped;    // non-finite samples dropped since the last mcrt_clear (mcrt_dropped_samples)
     unsigned long long* counters;   // 8 x u64 (kCount builds)
     uint32_t* pend;
     uint32_t s_begin, s_count, max_depth;
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_render(const RenderArgs a)
     RenderCounters rc = { 0, 0, 0 };
     RenderWork work = { a, 0u, 0u };
     trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount, kMulti>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, false, cn, rc, work, a.policy, walk_lds);
-    if (work.dropped_total) atomicAdd(a.tile_counter + 1, work.dropped_total);
+    if (work.dropped_total) atomicAdd(a.dropped, (unsigned long long)work.dropped_total);
     if (kCount) flush_counters(a.counters, cn, rc);
 }
 
@@ -572,6 +574,13 @@ __global__ __launch_bounds__(kBlock) void k_combine(double* __restrict__ accum, 
         for (uint32_t l = 1; l < slices; ++l) tot += partial[(uint64_t)l * values + i];
         accum[i] += tot;
     }
+}
+
+// accumulator += another accumulator of the same size (the contexts of one GPU, or a peer buffer): mcrt_add_accumulator
+__global__ __launch_bounds__(kBlock) void k_add(double* __restrict__ accum, const double* __restrict__ src, uint64_t values)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < values; i += stride) accum[i] += src[i];
 }
 
 struct ListArgs {
@@ -709,7 +718,8 @@ __global__ __launch_bounds__(kBlock) void k_unlit(const SceneView v, const Camer
     }
 }
 
-// source/main.cpp:142-164 + GLImageBuffer::SetPixel (source/opengl/data.cpp:28-50)
+// source/main.cpp:142-164 + GLImageBuffer::SetPixel (source/opengl/data.cpp:28-50).  pow / exp are the fixed-order pm_pow / pm_exp:
+// the bytes equal the oracle's (portable mode) on every input, and libm's wherever 255 * pow is not within ~1e-13 of an integer.
 __global__ __launch_bounds__(kBlock) void k_resolve(const double* __restrict__ sums, uint64_t npix, double spp, int tonemap, double inv_gamma,
                                                     double exposure, uint8_t* __restrict__ out_bgra, double* __restrict__ out_mean)
 {
@@ -722,10 +732,10 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const double* __restrict__ s
             if (out_mean) out_mean[3 * p + k] = x;
             if (tonemap == MCRT_TONEMAP_REINHARD) {
                 x = x / (x + 1.0);
-                x = pow(x, inv_gamma);
+                x = pm_pow(x, inv_gamma);
             } else if (tonemap == MCRT_TONEMAP_EXPOSURE) {
-                x = 1.0 - exp(-x * exposure);
-                x = pow(x, inv_gamma);
+                x = 1.0 - pm_exp(-x * exposure);
+                x = pm_pow(x, inv_gamma);
             }
             double t = (x < 1.0) ? x : 1.0;
             t = (t < 0.0) ? 0.0 : t;
@@ -781,6 +791,8 @@ struct mcrt_ctx {
     bool counting = false;
     unsigned long long* d_counters = nullptr;   // 8 x u64
     uint32_t* d_tile = nullptr;                 // 2 x u32
+    unsigned long long* d_dropped = nullptr;    // dropped (non-finite) samples since the last clear
+    uint32_t grid_mult = 4;                     // persistent workgroups per CU (MCRT_GRID_MULT, tuning knob)
     uint32_t* d_pend = nullptr;
     size_t pend_words = 0;
     uint32_t grid_blocks = 0;
@@ -846,8 +858,9 @@ void resolve_accel(mcrt_ctx* c)
         c->accel = (c->have_scene && c->view.nprim <= MCRT_SCAN_MAX_PRIMS) ? (flat_ok(c) ? MCRT_ACCEL_FLAT : MCRT_ACCEL_SCAN) : MCRT_ACCEL_OCTREE;
 }
 
-// persistent grid: enough 256-lane workgroups to fill every CU at the occupancy the kernel can reach
-uint32_t grid_for(const mcrt_ctx* c) { return (uint32_t)c->cu_count * 8u; }
+// persistent grid: the 256-lane workgroups that are resident together - every tracing kernel allocates 128 VGPRs, which is
+// 4 wavefronts per SIMD, 4 workgroups per CU; more would only queue behind them (and double the parked-branch stack)
+uint32_t grid_for(const mcrt_ctx* c) { return (uint32_t)c->cu_count * c->grid_mult; }
 
 int ensure_pend(mcrt_ctx* c, uint32_t max_depth)
 {
@@ -969,6 +982,42 @@ int need_scene(mcrt_ctx* c, bool camera)
     return bind_device(c);
 }
 
+// RCCL is bound at run time (dlopen), so that the library loads - and every single-GPU entry point works - where librccl is
+// absent, and a process that already carries an RCCL (PyTorch ships its own) is not given a second one: symbols already in
+// the process are preferred.  Enum values are those of rccl.h (ncclDouble = 8, ncclSum = 0).
+struct Rccl {
+    typedef int (*InitAll)(void** comms, int ndev, const int* devlist);
+    typedef int (*Destroy)(void* comm);
+    typedef int (*Reduce)(const void* send, void* recv, size_t count, int dtype, int op, int root, void* comm, hipStream_t stream);
+    typedef const char* (*ErrStr)(int);
+    InitAll init_all = nullptr;
+    Destroy destroy = nullptr;
+    Reduce reduce = nullptr;
+    ErrStr err = nullptr;
+    std::string why;
+    bool ok = false;
+};
+const Rccl& rccl()
+{
+    static const Rccl r = [] {
+        Rccl x;
+        void* h = RTLD_DEFAULT;
+        if (!dlsym(RTLD_DEFAULT, "ncclReduce")) {
+            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) { x.why = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?"); return x; }
+        }
+        x.init_all = (Rccl::InitAll)dlsym(h, "ncclCommInitAll");
+        x.destroy = (Rccl::Destroy)dlsym(h, "ncclCommDestroy");
+        x.reduce = (Rccl::Reduce)dlsym(h, "ncclReduce");
+        x.err = (Rccl::ErrStr)dlsym(h, "ncclGetErrorString");
+        x.ok = x.init_all && x.destroy && x.reduce;
+        if (!x.ok) x.why = "librccl lacks ncclCommInitAll / ncclCommDestroy / ncclReduce";
+        return x;
+    }();
+    return r;
+}
+
 template <class T> struct DevBuf {
     T* p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -1000,6 +1049,7 @@ int mcrt_create(int device_id, mcrt_ctx** out_ctx)
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("MCRT_MIN_TRACE")) { int r = atoi(e); if (r >= 0 && r <= 64) c->min_trace_override = r; }
+    if (const char* e = getenv("MCRT_GRID_MULT")) { int r = atoi(e); if (r >= 1 && r <= 16) c->grid_mult = (uint32_t)r; }
     if (const char* e = getenv("MCRT_REFILL")) { int r = atoi(e); if (r >= 0 && r <= 64) c->refill_override = r; }
     if (const char* e = getenv("MCRT_LEAF_CHUNK")) { int r = atoi(e); if (r > 0 && r < (1 << 20)) c->chunk_override = r; }
     if (const char* e = getenv("MCRT_FETCH_MIN")) { int r = atoi(e); if (r >= 1 && r <= 64) c->fetch_min_override = r; }
@@ -1010,6 +1060,8 @@ int mcrt_create(int device_id, mcrt_ctx** out_ctx)
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&c->d_tile, 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&c->d_dropped, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemset(c->d_dropped, 0, sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
     // with this context's device current: the address of THIS device's copy of the static staging array
     if ((e = hipGetSymbolAddress((void**)&c->noalloc_scratch, HIP_SYMBOL(scratch))) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
@@ -1027,6 +1079,7 @@ int mcrt_destroy(mcrt_ctx* c)
     if (c->d_accum_own) (void)hipFree(c->d_accum_own);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_tile) (void)hipFree(c->d_tile);
+    if (c->d_dropped) (void)hipFree(c->d_dropped);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_resolve_img) (void)hipFree(c->d_resolve_img);
     if (c->d_resolve_mean) (void)hipFree(c->d_resolve_mean);
@@ -1101,9 +1154,10 @@ int mcrt_set_camera(mcrt_ctx* c, const mcrt_camera* cam)
         if (c->d_accum_own) { HIP_TRY(c, hipFree(c->d_accum_own)); c->d_accum_own = nullptr; }
         HIP_TRY(c, hipMalloc(&c->d_accum_own, px * 3 * sizeof(double)));
         c->accum_pixels = px;
-        c->d_accum = c->d_accum_own;
+        c->d_accum = c->d_accum_own;         // a caller-bound buffer had the old size: back to the context's own (include/mcrt.h)
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_accum_own, 0, px * 3 * sizeof(double), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, px * 3 * sizeof(double), c->stream));     // the accumulator IN USE, bound or own
+    HIP_TRY(c, hipMemsetAsync(c->d_dropped, 0, sizeof(unsigned long long), c->stream));
     c->have_camera = true;
     return MCRT_OK;
 }
@@ -1307,6 +1361,19 @@ int mcrt_clear(mcrt_ctx* c)
     int rc = bind_device(c);
     if (rc) return rc;
     HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, c->accum_pixels * 3 * sizeof(double), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_dropped, 0, sizeof(unsigned long long), c->stream));
+    return MCRT_OK;
+}
+
+int mcrt_dropped_samples(mcrt_ctx* c, uint64_t* out)
+{
+    if (!c || !out) return MCRT_ERR_INVALID;
+    int rc = bind_device(c);
+    if (rc) return rc;
+    unsigned long long n = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n, c->d_dropped, sizeof n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *out = n;
     return MCRT_OK;
 }
 
@@ -1337,7 +1404,7 @@ int mcrt_render(mcrt_ctx* c, uint32_t sample_begin, uint32_t sample_count, uint3
     HIP_TRY(c, hipMemsetAsync(c->d_tile, 0, 2 * sizeof(uint32_t), c->stream));
     if (c->counting) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
     RenderArgs a;
-    a.view = view_for(c); a.cam = c->cam; a.accum = c->d_accum; a.tile_counter = c->d_tile; a.counters = c->d_counters; a.pend = c->d_pend;
+    a.view = view_for(c); a.cam = c->cam; a.accum = c->d_accum; a.tile_counter = c->d_tile; a.dropped = c->d_dropped; a.counters = c->d_counters; a.pend = c->d_pend;
     a.s_begin = sample_begin; a.s_count = sample_count; a.max_depth = max_depth;
     a.policy = lane_policy(c);
     a.slices = c->lanes_override ? std::min<uint32_t>(c->lanes_override, sample_count) : mcrt_lanes_per_pixel(c->cam.width, c->cam.height, sample_count);
@@ -1377,6 +1444,51 @@ int mcrt_render(mcrt_ctx* c, uint32_t sample_begin, uint32_t sample_count, uint3
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
+    return MCRT_OK;
+}
+
+int mcrt_add_accumulator(mcrt_ctx* c, const double* d_src)
+{
+    if (!c || !d_src) return MCRT_ERR_INVALID;
+    if (!c->have_camera) return fail(c, MCRT_ERR_STATE, "no camera set (mcrt_set_camera)");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    const uint64_t values = (uint64_t)c->accum_pixels * 3;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((values + kBlock - 1) / kBlock, 65535);
+    hipLaunchKernelGGL(k_add, dim3(blocks), dim3(kBlock), 0, c->stream, c->d_accum, d_src, values);
+    HIP_TRY(c, hipGetLastError());
+    return MCRT_OK;
+}
+
+int mcrt_comm_init_all(int n, const int* devices, void** out_comms)
+{
+    if (n <= 0 || !devices || !out_comms) return fail(nullptr, MCRT_ERR_INVALID, "mcrt_comm_init_all: bad arguments");
+    const Rccl& r = rccl();
+    if (!r.ok) return fail(nullptr, MCRT_ERR_NO_DEVICE, r.why);
+    const int e = r.init_all(out_comms, n, devices);
+    if (e != 0) return fail(nullptr, MCRT_ERR_HIP, std::string("ncclCommInitAll: ") + (r.err ? r.err(e) : "error"));
+    return MCRT_OK;
+}
+
+int mcrt_comm_destroy(void* comm)
+{
+    if (!comm) return MCRT_OK;
+    const Rccl& r = rccl();
+    if (!r.ok) return fail(nullptr, MCRT_ERR_NO_DEVICE, r.why);
+    return r.destroy(comm) == 0 ? MCRT_OK : fail(nullptr, MCRT_ERR_HIP, "ncclCommDestroy failed");
+}
+
+int mcrt_reduce(mcrt_ctx* c, void* comm, int root)
+{
+    if (!c || !comm) return MCRT_ERR_INVALID;
+    if (!c->have_camera) return fail(c, MCRT_ERR_STATE, "no camera set (mcrt_set_camera)");
+    const Rccl& r = rccl();
+    if (!r.ok) return fail(c, MCRT_ERR_NO_DEVICE, r.why);
+    int rc = bind_device(c);
+    if (rc) return rc;
+    // one collective per pass: the W*H*3 doubles of every rank summed into `root`, in place, on the context's stream
+    const int e = r.reduce(c->d_accum, c->d_accum, c->accum_pixels * 3, /*ncclDouble*/ 8, /*ncclSum*/ 0, root, comm, c->stream);
+    if (e != 0) return fail(c, MCRT_ERR_HIP, std::string("ncclReduce: ") + (r.err ? r.err(e) : "error"));
     return MCRT_OK;
 }
 

@@ -241,6 +241,80 @@ MCRT_DEV void pm_sin_and_tan(float alpha, float beta, float& sin_alpha, float& t
     }
 }
 
+// exp / log / pow in double for k_resolve (source/main.cpp:150-161), fixed operation order: the oracle's pm_exp / pm_log /
+// pm_pow (oracle/mcrt_oracle.c) operation by operation, so the BGRA8 bytes of a resolve are identical on device and host.
+// Within 1 ulp of libm (exp, log), ~1e-15 relative for pow = exp(y * log x).
+MCRT_DEV uint64_t pm_bits(double x) { return (uint64_t)__double_as_longlong(x); }
+MCRT_DEV double pm_from_bits(uint64_t u) { return __longlong_as_double((long long)u); }
+MCRT_DEV double pm_log(double x)      // finite x > 0
+{
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10,
+                 LG1 = 6.666666666666735130e-01, LG2 = 3.999999999940941908e-01, LG3 = 2.857142874366239149e-01,
+                 LG4 = 2.222219843214978396e-01, LG5 = 1.818357216161805012e-01, LG6 = 1.531383769920937332e-01,
+                 LG7 = 1.479819860511658591e-01;
+    long long k = 0;
+    uint64_t u = pm_bits(x);
+    if (u < 0x0010000000000000ull) { x = x * 18014398509481984.0; u = pm_bits(x); k = -54; }
+    k += (long long)(u >> 52) - 1023;
+    uint64_t m = u & 0x000FFFFFFFFFFFFFull;
+    if (m >= 0x0006A09E667F3BCDull) { k += 1; m |= 0x3FE0000000000000ull; }
+    else m |= 0x3FF0000000000000ull;
+    const double f = pm_from_bits(m) - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    double t1 = LG4 + w * LG6;
+    t1 = LG2 + w * t1;
+    t1 = w * t1;
+    double t2 = LG5 + w * LG7;
+    t2 = LG3 + w * t2;
+    t2 = LG1 + w * t2;
+    t2 = z * t2;
+    const double R = t2 + t1;
+    const double hfsq = (0.5 * f) * f;
+    const double dk = (double)k;
+    return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+}
+MCRT_DEV double pm_exp(double x)
+{
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10, INV_LN2 = 1.44269504088896338700e+00,
+                 P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 7.09782712893383973096e+02) return pm_from_bits(0x7FF0000000000000ull);
+    if (x < -7.45133219101941108420e+02) return 0.0;
+    const long long k = (long long)(INV_LN2 * x + (x < 0.0 ? -0.5 : 0.5));
+    const double t = (double)k;
+    const double hi = x - t * LN2_HI;
+    const double lo = t * LN2_LO;
+    const double r = hi - lo;
+    const double tt = r * r;
+    double p = P4 + tt * P5;
+    p = P3 + tt * p;
+    p = P2 + tt * p;
+    p = P1 + tt * p;
+    const double c = r - tt * p;
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    if (k >= -1021 && k <= 1022) return pm_from_bits(pm_bits(y) + ((uint64_t)k << 52));
+    if (k > 1022) return pm_from_bits(pm_bits(y) + ((uint64_t)(k - 2) << 52)) * 4.0;
+    return pm_from_bits(pm_bits(y) + ((uint64_t)(k + 1000) << 52)) * 9.33263618503218878990e-302;   // 2^-1000
+}
+MCRT_DEV double pm_pow(double x, double y)
+{
+    if (y == 1.0) return x;
+    if (y == 0.0) return 1.0;
+    if (x != x || y != y) return x + y;
+    double sign = 1.0;
+    if (x < 0.0) {
+        if (y != floor(y)) return __builtin_nan("");
+        if (fabs(y) < 9007199254740992.0 && floor(y * 0.5) * 2.0 != y) sign = -1.0;
+        x = -x;
+    }
+    if (x == 0.0) return y > 0.0 ? 0.0 * sign : pm_from_bits(0x7FF0000000000000ull) * sign;
+    if (x > 1.79769313486231570815e+308) return y > 0.0 ? x * sign : 0.0 * sign;
+    return sign * pm_exp(y * pm_log(x));
+}
+
 // ------------------------------------------------------------- primitives
 // Triangle::Intersects, source/core/triangle.h:25-62 (edges precomputed at upload).
 MCRT_DEV bool tri_hit_rec(const TriRec& tr, V3 o, V3 d, float& t)

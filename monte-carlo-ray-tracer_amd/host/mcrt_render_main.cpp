@@ -4,20 +4,40 @@
 //   main.cpp:100-184   render loop            -> Scene::Render (GPU), progressive passes
 //   main.cpp:142-164   tonemap + 8-bit store  -> Scene::Resolve (GPU)
 //   screenshot.cpp     PNG of the framebuffer -> binary PPM (P6) of the BGRA8 buffer
+//   main.cpp:59-62,250-262   one worker thread per hardware thread -> --devices: one thread + context per GPU
+//   main.cpp:70-86     RAY_TRACE_RANDOM pixel picks -> --random-pixels
 //
 // Usage: mcrt_render [--scene cornell|hexagon] [--width W] [--height H] [--spp N] [--pass P]
 //                    [--depth D] [--seed S] [--tonemap reinhard|exposure|none] [--gamma G]
 //                    [--exposure E] [--point-light] [--obj FILE x y z] [--unlit] [--device I]
+//                    [--devices I,J,...] [--random-pixels N [--pick-seed S]]
 //                    [--out image.ppm] [--raw accum.f64] [--checkpoint FILE] [--resume FILE]
+//
+// --devices I,J,...  one context and one host thread per listed GPU.  Every pass of P samples per pixel is split
+// into contiguous ranges of global sample indices, one per device (the first P % n devices take one sample more);
+// the streams are keyed by the global sample index, so the image does not depend on the device list beyond
+// summation order.  After a pass the accumulators are summed into the first device's (ONE ncclReduce of W*H*3
+// doubles over RCCL, mcrt_reduce), which resolves; the others start their next pass from zero.  A device listed
+// more than once (--devices 0,0: several contexts sharing one GPU) is served by a plain device add instead
+// (mcrt_add_accumulator); the list is either all distinct or all the same device.
+//
+// --random-pixels N  the reference's default scheduler (RAY_TRACE_RANDOM, main.cpp:40,70-86): N times, pick a
+// pixel with two draws of the driver's generator (seeded by --pick-seed: the reference seeds it from
+// std::random_device), trace ONE sample of it and accumulate; a pixel's k-th pick is its sample index k.  Every
+// pixel is normalised by its own ray count (main.cpp:142).  --spp / --pass are not used in this mode.
 //
 // --checkpoint FILE rewrites FILE after every pass (header: magic, width, height, samples done, seed; then the
 // W*H*3 accumulator doubles); --resume FILE continues such a render: samples [done, spp) are rendered on top of
 // the stored sums.  The reference has nothing comparable (its accumulators live and die with the process).
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mcrt_scene.hpp"
@@ -59,6 +79,22 @@ bool ReadCheckpoint(const std::string& path, unsigned width, unsigned height, ui
     return ok;
 }
 
+// all threads of a multi-device render meet here (C++17 has no std::barrier)
+class Barrier {
+    std::mutex m;
+    std::condition_variable cv;
+    unsigned n, waiting = 0, generation = 0;
+public:
+    explicit Barrier(unsigned count) : n(count) {}
+    void Wait()
+    {
+        std::unique_lock<std::mutex> lock(m);
+        const unsigned gen = generation;
+        if (++waiting == n) { waiting = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lock, [&] { return gen != generation; });
+    }
+};
+
 bool WritePPM(const std::string& path, const std::vector<uint8_t>& bgra, int w, int h)
 {
     FILE* f = std::fopen(path.c_str(), "wb");
@@ -81,11 +117,11 @@ int main(int argc, char** argv)
 {
     std::string sceneName = "cornell", out = "render.ppm", raw, tonemapName = "reinhard", objPath, checkpoint, resume;
     unsigned width = 640, height = 480, spp = 64, pass = 64, depth = 100;   // main.cpp:33-41 defaults
-    uint64_t seed = 0x5EED0001ull;
+    uint64_t seed = 0x5EED0001ull, pickSeed = 1, randomPixels = 0;
     double gamma = 2.2, exposure = 1.0;                                     // main.cpp:47-48
     float objPos[3] = { 0, 0, 0 };
     bool pointLight = false, unlit = false;
-    int device = 0;
+    std::vector<int> devices;
     for (int i = 1; i < argc; ++i) {
         auto next = [&](const char* flag) -> const char* {
             if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", flag); std::exit(2); }
@@ -99,10 +135,21 @@ int main(int argc, char** argv)
         else if (a == "--pass") pass = unsigned(std::atoi(next("--pass")));
         else if (a == "--depth") depth = unsigned(std::atoi(next("--depth")));
         else if (a == "--seed") seed = std::strtoull(next("--seed"), nullptr, 0);
+        else if (a == "--pick-seed") pickSeed = std::strtoull(next("--pick-seed"), nullptr, 0);
+        else if (a == "--random-pixels") randomPixels = std::strtoull(next("--random-pixels"), nullptr, 0);
         else if (a == "--tonemap") tonemapName = next("--tonemap");
         else if (a == "--gamma") gamma = std::atof(next("--gamma"));
         else if (a == "--exposure") exposure = std::atof(next("--exposure"));
-        else if (a == "--device") device = std::atoi(next("--device"));
+        else if (a == "--device") devices.assign(1, std::atoi(next("--device")));
+        else if (a == "--devices") {
+            devices.clear();
+            for (const char* p = next("--devices"); *p;) {
+                char* end = nullptr;
+                devices.push_back(int(std::strtol(p, &end, 10)));
+                if (end == p) { std::fprintf(stderr, "--devices wants a comma-separated list of device indices\n"); return 2; }
+                p = (*end == ',') ? end + 1 : end;
+            }
+        }
         else if (a == "--out") out = next("--out");
         else if (a == "--raw") raw = next("--raw");
         else if (a == "--checkpoint") checkpoint = next("--checkpoint");
@@ -112,37 +159,62 @@ int main(int argc, char** argv)
         else if (a == "--obj") { objPath = next("--obj"); for (float& v : objPos) v = float(std::atof(next("--obj"))); }
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
+    if (devices.empty()) devices.push_back(0);
     if (pass == 0 || pass > spp) pass = spp;
     const int tonemap = tonemapName == "none" ? MCRT_TONEMAP_NONE : tonemapName == "exposure" ? MCRT_TONEMAP_EXPOSURE : MCRT_TONEMAP_REINHARD;
+    const unsigned nDev = unsigned(devices.size());
+    bool distinct = true, same = true;
+    for (unsigned i = 0; i < nDev; ++i)
+        for (unsigned j = i + 1; j < nDev; ++j) { if (devices[i] == devices[j]) distinct = false; else same = false; }
+    if (nDev > 1 && !distinct && !same) { std::fprintf(stderr, "--devices: list every GPU once, or one GPU several times\n"); return 2; }
+    if (nDev > 1 && (unlit || randomPixels)) { std::fprintf(stderr, "--unlit and --random-pixels run on one device\n"); return 2; }
 
-    Camera camera{ width, height, 90.0f };                                  // CAMERA_FOV, main.cpp:37
-    Scene* scene = nullptr;
-    if (sceneName == "hexagon") {
-        HexagonScene* s = new HexagonScene();
-        s->MoveCameraToRecommendedPosition(camera);
-        s->AddExampleObjects();
-        s->AddExampleLight(ColorDbl{ 10.0 }, pointLight);
-        scene = s;
-    } else {
-        CornellBoxScene* s = new CornellBoxScene{ 10.0f, 10.0f, 10.0f };
-        s->backgroundColor = { 0.0, 0.0, 0.0 };
-        s->MoveCameraToRecommendedPosition(camera);
-        s->AddExampleObjects();
-        s->AddExampleLight(ColorDbl{ 10.0 }, pointLight);                   // LIGHT_STRENGTH, main.cpp:43
-        scene = s;
+    // one scene + camera per device (main.cpp:234-242): the description is replicated, every GPU holds its own image of it
+    std::vector<std::unique_ptr<Scene>> scenes;
+    std::vector<std::unique_ptr<Camera>> cameras;
+    for (unsigned r = 0; r < nDev; ++r) {
+        cameras.emplace_back(new Camera{ width, height, 90.0f });               // CAMERA_FOV, main.cpp:37
+        Camera& camera = *cameras.back();
+        Scene* scene = nullptr;
+        if (sceneName == "hexagon") {
+            HexagonScene* s = new HexagonScene();
+            s->MoveCameraToRecommendedPosition(camera);
+            s->AddExampleObjects();
+            s->AddExampleLight(ColorDbl{ 10.0 }, pointLight);
+            scene = s;
+        } else {
+            CornellBoxScene* s = new CornellBoxScene{ 10.0f, 10.0f, 10.0f };
+            s->backgroundColor = { 0.0, 0.0, 0.0 };
+            s->MoveCameraToRecommendedPosition(camera);
+            s->AddExampleObjects();
+            s->AddExampleLight(ColorDbl{ 10.0 }, pointLight);                   // LIGHT_STRENGTH, main.cpp:43
+            scene = s;
+        }
+        scenes.emplace_back(scene);
+        if (!objPath.empty()) {
+            TriangleMesh* mesh = scene->CreateObject<TriangleMesh>();
+            mesh->position = vec3(objPos[0], objPos[1], objPos[2]);
+            mesh->material.color = ColorDbl(0.5);
+            if (!mesh->LoadMesh(objPath)) return 1;
+        }
+        scene->UseDevice(devices[r]);
+        scene->PrepareForRayTracing();
+        if (!scene->Context()) return 1;
     }
-    if (!objPath.empty()) {
-        TriangleMesh* mesh = scene->CreateObject<TriangleMesh>();
-        mesh->position = vec3(objPos[0], objPos[1], objPos[2]);
-        mesh->material.color = ColorDbl(0.5);
-        if (!mesh->LoadMesh(objPath)) return 1;
-    }
-    scene->UseDevice(device);
-    scene->PrepareForRayTracing();
-    if (!scene->Context()) return 1;
+    Scene* scene = scenes[0].get();
+    Camera& camera = *cameras[0];
     scene->octree.PrintDebug();
 
+    std::vector<void*> comms(nDev, nullptr);
+    if (nDev > 1 && distinct) {
+        if (mcrt_comm_init_all(int(nDev), devices.data(), comms.data()) != MCRT_OK) {
+            std::fprintf(stderr, "mcrt_comm_init_all: %s\n", mcrt_last_error(nullptr));
+            return 1;
+        }
+    }
+
     std::vector<uint8_t> image;
+    uint64_t samplesTraced = 0;
     const auto t0 = std::chrono::steady_clock::now();
     if (unlit) {
         // RAY_TRACE_UNLIT, main.cpp:39,124-135
@@ -156,6 +228,34 @@ int main(int argc, char** argv)
             for (int k = 0; k < 3; ++k) image[p * 4 + size_t(2 - k)] = uint8_t(std::max(std::min(1.0, colour[p * 3 + size_t(k)]), 0.0) * 255.0);
             image[p * 4 + 3] = 255;
         }
+    } else if (randomPixels) {
+        // GetNextPixelToRender with RAY_TRACE_RANDOM (main.cpp:70-86) + the one-sample loop of RayTraceNextPixel (:122-139).
+        // The picks of a batch are drawn first (they depend on the driver's generator alone), traced together on the
+        // GPU, and accumulated in pick order - the sum a single reference thread would build.
+        UniformRandomGenerator picker(pickSeed, pickSeed ^ 0x9E3779B97F4A7C15ull);
+        std::vector<uint32_t> nextSample(size_t(width) * height, 0), pixels, samples;
+        std::vector<double> radiance;
+        const uint64_t batch = 1u << 20;
+        for (uint64_t done = 0; done < randomPixels; done += batch) {
+            const uint64_t n = std::min<uint64_t>(batch, randomPixels - done);
+            pixels.resize(n); samples.resize(n);
+            for (uint64_t i = 0; i < n; ++i) {
+                unsigned x = (unsigned int)(picker.RandomFloat(0.0f, float(width)));
+                unsigned y = (unsigned int)(picker.RandomFloat(0.0f, float(height)));
+                x = std::min(x, width - 1);
+                y = std::min(y, height - 1);
+                pixels[i] = y * width + x;
+                samples[i] = nextSample[pixels[i]]++;
+            }
+            if (!scene->TraceSamples(camera, pixels, samples, seed, depth, radiance)) return 1;
+            for (uint64_t i = 0; i < n; ++i) {
+                const ColorDbl c(radiance[3 * i], radiance[3 * i + 1], radiance[3 * i + 2]);
+                if (!(std::isfinite(c.r) && std::isfinite(c.g) && std::isfinite(c.b))) continue;    // dropped, as in Scene::Render (stated deviation)
+                camera.pixels.Accumulate(pixels[i] % width, pixels[i] / width, c);
+            }
+            if (!scene->ResolvePerPixelCounts(camera, tonemap, gamma, exposure, image)) return 1;  // what the window would show now
+        }
+        samplesTraced = randomPixels;
     } else {
         unsigned first = 0;
         if (!resume.empty()) {
@@ -169,20 +269,56 @@ int main(int argc, char** argv)
             first = unsigned(samples);
             std::printf("Resumed at %u of %u spp\r\n", first, spp);
         }
-        for (unsigned done = first; done < spp; done += pass) {
-            const unsigned n = std::min(pass, spp - done);
-            if (!scene->Render(camera, done, n, depth, seed)) return 1;
-            if (!scene->Resolve(camera, tonemap, gamma, exposure, image)) return 1;      // what the window would show after this pass
-            if (!checkpoint.empty() && !WriteCheckpoint(checkpoint, *scene, camera, done + n, seed)) { std::fprintf(stderr, "cannot write %s\n", checkpoint.c_str()); return 1; }
-        }
+        // One worker per device.  Rank 0 (the first device) holds the job's sums, resolves and checkpoints.
+        Barrier barrier(nDev);
+        std::vector<int> failed(nDev, 0);
+        auto worker = [&](unsigned r) {
+            Scene& sc = *scenes[r];
+            Camera& cam = *cameras[r];
+            bool ok = true;
+            for (unsigned done = first; done < spp; done += pass) {
+                const unsigned n = std::min(pass, spp - done);
+                // this rank's share of the window [done, done + n): contiguous, sizes differ by at most one
+                const unsigned base = n / nDev, extra = n % nDev;
+                const unsigned mine = base + (r < extra ? 1u : 0u), begin = done + r * base + std::min(r, extra);
+                // a rank with no sample in this window still binds its camera (the reduce needs its zeroed accumulator)
+                ok = ok && sc.Render(cam, begin, mine, depth, seed);
+                if (nDev > 1) {
+                    if (distinct) ok = ok && sc.Reduce(cam, comms[r], 0);
+                    else {
+                        ok = ok && mcrt_synchronize(sc.Context()) == MCRT_OK;
+                        barrier.Wait();                                          // every context's pass is complete
+                        if (r == 0) for (unsigned j = 1; j < nDev && ok; ++j) ok = sc.AddAccumulatorOf(cam, *scenes[j]);
+                        if (r == 0) ok = ok && mcrt_synchronize(sc.Context()) == MCRT_OK;
+                        barrier.Wait();                                          // rank 0 has read the others' sums
+                    }
+                    if (r != 0) ok = ok && sc.Clear(cam);                        // their sums now live on rank 0
+                }
+                if (r == 0) {
+                    sc.SetSampleCount(cam, done + n);
+                    ok = ok && sc.Resolve(cam, tonemap, gamma, exposure, image);      // what the window would show after this pass
+                    if (ok && !checkpoint.empty() && !WriteCheckpoint(checkpoint, sc, cam, done + n, seed)) { std::fprintf(stderr, "cannot write %s\n", checkpoint.c_str()); ok = false; }
+                }
+            }
+            failed[r] = ok ? 0 : 1;
+        };
+        std::vector<std::thread> threads;
+        for (unsigned r = 1; r < nDev; ++r) threads.emplace_back(worker, r);
+        worker(0);
+        for (std::thread& t : threads) t.join();
+        for (unsigned r = 0; r < nDev; ++r) if (failed[r]) { std::fprintf(stderr, "render failed on device %d\n", devices[r]); return 1; }
         if (first >= spp && !scene->Resolve(camera, tonemap, gamma, exposure, image)) return 1;
+        samplesTraced = uint64_t(width) * height * (spp - std::min(first, spp));
     }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::printf("Render finished at %.3f s: %ux%u, %u spp, %.1f Msamples/s\r\n", secs, width, height, spp,
-                unlit ? 0.0 : double(width) * height * spp / secs / 1e6);
+    std::printf("Render finished at %.3f s: %ux%u, %u spp, %u device(s), %.1f Msamples/s\r\n", secs, width, height, randomPixels ? 0u : spp, nDev,
+                double(samplesTraced) / secs / 1e6);
+    uint64_t droppedTotal = 0;
+    for (auto& sc : scenes) { uint64_t d = 0; if (mcrt_dropped_samples(sc->Context(), &d) == MCRT_OK) droppedTotal += d; }
+    if (droppedTotal) std::printf("%llu non-finite samples dropped\r\n", (unsigned long long)droppedTotal);
     if (!WritePPM(out, image, int(width), int(height))) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
     if (!raw.empty() && !unlit) {
-        if (!scene->ReadBack(camera)) return 1;
+        if (!randomPixels && !scene->ReadBack(camera)) return 1;
         FILE* f = std::fopen(raw.c_str(), "wb");
         if (!f) return 1;
         for (unsigned y = 0; y < height; ++y)
@@ -192,6 +328,6 @@ int main(int argc, char** argv)
             }
         std::fclose(f);
     }
-    delete scene;
+    for (void* c : comms) if (c) mcrt_comm_destroy(c);
     return 0;
 }

@@ -32,6 +32,19 @@ UniformRandomGenerator::UniformRandomGenerator()
     xorseed[0] = (uint64_t(rd()) << 32) ^ (rd());
     xorseed[1] = (uint64_t(rd()) << 32) ^ (rd());
 }
+// RandomInt + to_double, source/core/randomization.h:23-43
+double UniformRandomGenerator::RandomDouble()
+{
+    uint64_t x = xorseed[0];
+    const uint64_t y = xorseed[1];
+    xorseed[0] = y;
+    x ^= x << 23;
+    xorseed[1] = x ^ y ^ (x >> 17) ^ (y >> 26);
+    const uint64_t bits = (0x3FFull << 52) | ((xorseed[1] + y) >> 12);
+    double d;
+    std::memcpy(&d, &bits, sizeof d);
+    return d - 1.0;
+}
 UniformRandomGenerator UniformRandomGenerator::ForSample(uint64_t seed, uint32_t pixel, uint32_t sample)
 {
     uint64_t st[2];
@@ -152,6 +165,13 @@ PixelBuffer::PixelBuffer(unsigned int width, unsigned int height) : imageWidth(w
     dy = 2.0 / double(imageHeight);
     aspect = imageWidth / double(imageHeight);
 }
+void PixelBuffer::Accumulate(unsigned int x, unsigned int y, ColorDbl color)
+{
+    const unsigned int i = PixelArrayIndex(x, y);
+    data[i] += color.r; data[i + 1] += color.g; data[i + 2] += color.b;
+    if (rayCount.empty()) rayCount.assign(size_t(imageWidth) * imageHeight, 0);
+    rayCount[size_t(y) * imageWidth + x]++;
+}
 ColorDbl PixelBuffer::GetPixelColor(unsigned int x, unsigned int y)
 {
     const unsigned int i = PixelArrayIndex(x, y);
@@ -170,6 +190,23 @@ void Camera::SetView(vec3 position, vec3 lookAtPosition, vec3 cameraUp)
     const float p[3] = { position.x, position.y, position.z }, t[3] = { lookAtPosition.x, lookAtPosition.y, lookAtPosition.z };
     const float u[3] = { cameraUp.x, cameraUp.y, cameraUp.z };
     mcrt_camera_look_at(view.width, view.height, fov, p, t, u, &view);
+}
+
+Ray Camera::GetPixelRay(float x, float y) const
+{
+    // normalised coordinates, y = 0 is the top row; the products are evaluated in double and narrowed (camera.h:40-44)
+    vec3 direction(float(-1.0f + x * pixels.deltaX()), float(1.0f - y * pixels.deltaY()), -1.0f);
+    direction.x *= view.fov_scale * float(pixels.aspectRatio());        // camera.h:48-49
+    direction.y *= view.fov_scale;
+    // vec3(viewMatrix * vec4(direction, 0)): glm's mat4 * vec4, include/glm/detail/type_mat4x4.inl (Mul0 + Mul1) + (Mul2 + Mul3)
+    const float* m = view.view;
+    float r[3];
+    for (int k = 0; k < 3; ++k) {
+        const float add0 = m[0 + k] * direction.x + m[4 + k] * direction.y;
+        const float add1 = m[8 + k] * direction.z + m[12 + k] * 0.0f;
+        r[k] = add0 + add1;
+    }
+    return Ray(vec3(view.position[0], view.position[1], view.position[2]), normalize(vec3(r[0], r[1], r[2])));
 }
 
 void Octree::PrintDebug() const
@@ -271,7 +308,64 @@ void Scene::PrepareForRayTracing()
     prepared = true;
 }
 
-bool Scene::IntersectRay(Ray& ray, RayIntersectionInfo& hitInfo)
+bool Scene::Bind(Camera& camera)
+{
+    if (boundCamera == &camera) return true;
+    if (mcrt_set_camera(ctx, &camera.view) != MCRT_OK) return Fail("set_camera");
+    boundCamera = &camera;
+    camera.pixels.rays = 0;
+    return true;
+}
+
+bool Scene::TraceSamples(Camera& camera, const std::vector<uint32_t>& pixels, const std::vector<uint32_t>& samples, uint64_t seed,
+                         unsigned int traceDepth, std::vector<double>& radiance)
+{
+    if (!prepared) return Fail("TraceSamples before PrepareForRayTracing");
+    if (pixels.size() != samples.size()) return Fail("TraceSamples: pixel and sample lists differ in length");
+    if (!Bind(camera)) return false;
+    radiance.resize(pixels.size() * 3);
+    return mcrt_trace_samples(ctx, pixels.size(), pixels.data(), samples.data(), seed, traceDepth, radiance.data()) == MCRT_OK || Fail("trace_samples");
+}
+
+bool Scene::ResolvePerPixelCounts(Camera& camera, int tonemap, double gamma, double exposure, std::vector<uint8_t>& bgra8)
+{
+    if (!prepared) return Fail("Resolve before PrepareForRayTracing");
+    if (!Bind(camera)) return false;
+    // the device resolves sums / spp_total with one count for the image: hand it the per-pixel means and a count of 1
+    // (x / 1.0 is exact), so the tonemap and the 8-bit store stay the device's
+    PixelBuffer& pb = camera.pixels;
+    std::vector<double> mean(pb.data.size(), 0.0);
+    for (size_t p = 0; p < size_t(pb.numPixels()); ++p) {
+        const uint64_t n = pb.rays + (pb.rayCount.empty() ? 0u : pb.rayCount[p]);
+        if (n == 0) continue;
+        for (size_t k = 0; k < 3; ++k) mean[p * 3 + k] = pb.data[p * 3 + k] / double(n);
+    }
+    // the device accumulator is borrowed for the means and put back afterwards
+    std::vector<double> keep(pb.data.size());
+    if (mcrt_read_accumulator(ctx, keep.data()) != MCRT_OK) return Fail("read_accumulator");
+    if (mcrt_write_accumulator(ctx, mean.data()) != MCRT_OK) return Fail("write_accumulator");
+    bgra8.resize(size_t(pb.numPixels()) * 4);
+    const bool ok = mcrt_resolve(ctx, tonemap, gamma, exposure, 1, bgra8.data(), nullptr) == MCRT_OK;
+    if (mcrt_write_accumulator(ctx, keep.data()) != MCRT_OK) return Fail("write_accumulator");
+    return ok || Fail("resolve");
+}
+
+bool Scene::Reduce(Camera& camera, void* ncclComm, int root)
+{
+    if (boundCamera != &camera) return Fail("Reduce: camera not rendered with this scene");
+    return mcrt_reduce(ctx, ncclComm, root) == MCRT_OK || Fail("reduce");
+}
+
+bool Scene::AddAccumulatorOf(Camera& camera, Scene& other)
+{
+    if (boundCamera != &camera || !other.ctx) return Fail("AddAccumulatorOf: camera not rendered with this scene");
+    if (other.device != device) return Fail("AddAccumulatorOf: the other context lives on another GPU (use Reduce)");
+    double* src = nullptr;
+    if (mcrt_synchronize(other.ctx) != MCRT_OK || mcrt_accumulator(other.ctx, &src) != MCRT_OK) return Fail("AddAccumulatorOf: other context");
+    return mcrt_add_accumulator(ctx, src) == MCRT_OK || Fail("add_accumulator");
+}
+
+bool Scene::IntersectRay(Ray& ray, RayIntersectionInfo& hitInfo) const
 {
     hitInfo.Reset();
     if (!prepared) return Fail("IntersectRay before PrepareForRayTracing");
@@ -306,11 +400,7 @@ ColorDbl Scene::TraceRay(Ray ray, UniformRandomGenerator& uniformGenerator, unsi
 bool Scene::Render(Camera& camera, uint32_t sampleBegin, uint32_t sampleCount, unsigned int traceDepth, uint64_t seed)
 {
     if (!prepared) return Fail("Render before PrepareForRayTracing");
-    if (boundCamera != &camera) {
-        if (mcrt_set_camera(ctx, &camera.view) != MCRT_OK) return Fail("set_camera");
-        boundCamera = &camera;
-        camera.pixels.rays = 0;
-    }
+    if (!Bind(camera)) return false;
     if (mcrt_render(ctx, sampleBegin, sampleCount, traceDepth, seed) != MCRT_OK) return Fail("render");
     camera.pixels.rays += sampleCount;
     return true;
@@ -333,10 +423,7 @@ bool Scene::Restore(Camera& camera, const std::vector<double>& sums, uint64_t sa
 {
     if (!prepared) return Fail("Restore before PrepareForRayTracing");
     if (sums.size() != size_t(camera.pixels.numPixels()) * 3) return Fail("Restore: wrong accumulator size");
-    if (boundCamera != &camera) {
-        if (mcrt_set_camera(ctx, &camera.view) != MCRT_OK) return Fail("set_camera");
-        boundCamera = &camera;
-    }
+    if (!Bind(camera)) return false;
     if (mcrt_write_accumulator(ctx, sums.data()) != MCRT_OK) return Fail("write_accumulator");
     camera.pixels.rays = samplesDone;
     return true;
@@ -548,6 +635,41 @@ int mcrt_host_scene_add_obj(void* scene, const char* path, float px, float py, f
 }
 
 // Pointers stay valid until the next call on the same scene.
+// Camera::Camera + SetView + GetPixelRay on the host, for n pixel positions (test hook)
+void mcrt_host_camera_rays(unsigned width, unsigned height, float fov_y, const float pos[3], const float target[3], const float up[3], uint64_t n,
+                           const float* xs, const float* ys, float* out_o, float* out_d)
+{
+    Camera cam{ width, height, fov_y };
+    cam.SetView(vec3(pos[0], pos[1], pos[2]), vec3(target[0], target[1], target[2]), vec3(up[0], up[1], up[2]));
+    for (uint64_t i = 0; i < n; ++i) {
+        const Ray r = cam.GetPixelRay(xs[i], ys[i]);
+        out_o[3 * i] = r.origin.x; out_o[3 * i + 1] = r.origin.y; out_o[3 * i + 2] = r.origin.z;
+        out_d[3 * i] = r.direction.x; out_d[3 * i + 1] = r.direction.y; out_d[3 * i + 2] = r.direction.z;
+    }
+}
+
+// UniformRandomGenerator::RandomDouble on the host (test hook)
+void mcrt_host_rng_doubles(uint64_t s0, uint64_t s1, uint64_t n, double* out)
+{
+    UniformRandomGenerator g(s0, s1);
+    for (uint64_t i = 0; i < n; ++i) out[i] = g.RandomDouble();
+}
+
+// PixelBuffer::Accumulate / GetPixelColor / GetRayCount (test hook): n samples added one by one
+void mcrt_host_accumulate(unsigned width, unsigned height, uint64_t n, const uint32_t* xs, const uint32_t* ys, const double* colors, double* out_sums,
+                          uint64_t* out_counts)
+{
+    PixelBuffer pb{ width, height };
+    for (uint64_t i = 0; i < n; ++i) pb.Accumulate(xs[i], ys[i], ColorDbl(colors[3 * i], colors[3 * i + 1], colors[3 * i + 2]));
+    for (unsigned y = 0; y < height; ++y)
+        for (unsigned x = 0; x < width; ++x) {
+            const ColorDbl c = pb.GetPixelColor(x, y);
+            double* o = out_sums + (size_t(y) * width + x) * 3;
+            o[0] = c.r; o[1] = c.g; o[2] = c.b;
+            out_counts[size_t(y) * width + x] = pb.GetRayCount(x, y);
+        }
+}
+
 int mcrt_host_scene_flatten(void* scene, mcrt_scene_desc* out) { return static_cast<Scene*>(scene)->Flatten(*out) ? 0 : 1; }
 
 int mcrt_host_scene_prepare(void* scene)

@@ -72,8 +72,9 @@ struct Triangle {
     Triangle(const vec3& v0, const vec3& v1, const vec3& v2);
 };
 
-// xorshift128+ state holder.  Draws happen on the device; the host object only
-// carries the 128-bit state in and out of Scene::TraceRay.
+// xorshift128+.  The draws of a PATH happen on the device: the host object carries the 128-bit state in and out of
+// Scene::TraceRay.  The host-side draws below serve the driver's own generator - the pixel picks of the random-pixel
+// scheduler, source/main.cpp:27,78-79 - with the reference's arithmetic (source/core/randomization.h:23-43, .cpp:15-33).
 class UniformRandomGenerator {
 public:
     uint64_t xorseed[2] = { 0, 0 };
@@ -81,6 +82,10 @@ public:
     UniformRandomGenerator(uint64_t a, uint64_t b) { xorseed[0] = a; xorseed[1] = b; }
     // state for camera sample (seed, pixel, sample): the counter mapping of mcrt_rng_seed
     static UniformRandomGenerator ForSample(uint64_t seed, uint32_t pixel, uint32_t sample);
+    double RandomDouble();
+    double RandomDouble(double min, double max) { return min + (max - min) * RandomDouble(); }
+    float RandomFloat() { return float(RandomDouble()); }
+    float RandomFloat(float min, float max) { return min + (max - min) * float(RandomDouble()); }
 };
 
 class Object {
@@ -132,8 +137,9 @@ class PixelBuffer {
 protected:
     unsigned int dataSize = 0, imageWidth = 0, imageHeight = 0;
     double dx = 0.0, dy = 0.0, aspect = 1.0;
-    std::vector<double> data;                                      // accumulator sums, filled by Camera::ReadBack
-    uint64_t rays = 0;                                             // samples per pixel accumulated so far
+    std::vector<double> data;                                      // accumulator sums: Scene::ReadBack and Accumulate
+    uint64_t rays = 0;                                             // samples every pixel has from Scene::Render passes
+    std::vector<uint64_t> rayCount;                                // per pixel, on top of `rays`: samples added one by one (Accumulate)
     friend class Camera;
     friend class Scene;
 public:
@@ -146,7 +152,9 @@ public:
     double deltaY() const { return dy; }
     double aspectRatio() const { return aspect; }
     unsigned int PixelArrayIndex(unsigned int x, unsigned int y) { return y * imageWidth * 3 + x * 3; }
-    uint64_t GetRayCount(unsigned int) { return rays; }
+    // source/core/pixelbuffer.cpp:39-62 (the reference indexes its ray counts with the colour index, :45,:58-61)
+    void Accumulate(unsigned int x, unsigned int y, ColorDbl color);
+    uint64_t GetRayCount(unsigned int x, unsigned int y) { return rays + (rayCount.empty() ? 0u : rayCount[size_t(y) * imageWidth + x]); }
     ColorDbl GetPixelColor(unsigned int x, unsigned int y);
 };
 
@@ -159,6 +167,8 @@ public:
     PixelBuffer pixels;
     Camera(unsigned int width, unsigned int height, float fovY);
     void SetView(vec3 position, vec3 lookAtPosition, vec3 cameraUp = vec3{ 0.0f, 1.0f, 0.0f });
+    // source/core/camera.h:36-57, on the host, operation by operation (the kernels' camera_ray is the same sequence)
+    Ray GetPixelRay(float x, float y) const;
     const mcrt_camera& Description() const { return view; }
 };
 
@@ -187,6 +197,7 @@ protected:
     const Camera* boundCamera = nullptr;
     bool EnsureContext();
     bool Fail(const char* what) const;
+    bool Bind(Camera& camera);                                       // mcrt_set_camera once per (scene, camera)
 public:
     Octree octree;
     ColorDbl backgroundColor = { 0.0, 0.0, 0.0 };
@@ -212,7 +223,7 @@ public:
     // The flat description PrepareForRayTracing uploads (no device needed).
     bool Flatten(mcrt_scene_desc& out);
 
-    bool IntersectRay(Ray& ray, RayIntersectionInfo& hitInfo);
+    bool IntersectRay(Ray& ray, RayIntersectionInfo& hitInfo) const;      // source/scene.h:41
     ColorDbl TraceUnlit(Ray ray);
     double MaxImportance(ColorDbl& importance)
     {
@@ -228,6 +239,23 @@ public:
     bool Restore(Camera& camera, const std::vector<double>& sums, uint64_t samplesDone);
     bool Resolve(Camera& camera, int tonemap, double gamma, double exposure, std::vector<uint8_t>& bgra8);
     bool Clear(Camera& camera);
+
+    // Per-sample radiance of an explicit (pixel, sample index) list: what one RayTraceNextPixel call computes for a
+    // randomly picked pixel (source/main.cpp:70-86,122-139); the caller adds the values with PixelBuffer::Accumulate.
+    bool TraceSamples(Camera& camera, const std::vector<uint32_t>& pixels, const std::vector<uint32_t>& samples, uint64_t seed,
+                      unsigned int traceDepth, std::vector<double>& radiance);
+    // camera.pixels (sums and per-pixel ray counts filled by PixelBuffer::Accumulate) -> 8-bit image: the mean of every
+    // pixel over ITS OWN ray count (source/main.cpp:142), pixels never picked stay black
+    bool ResolvePerPixelCounts(Camera& camera, int tonemap, double gamma, double exposure, std::vector<uint8_t>& bgra8);
+
+    // Several GPUs (or several contexts of one GPU), one Scene + Camera each, every one rendering its own share of the
+    // sample indices - the worker threads of source/main.cpp:59-62,250-262 turned into one context per device.
+    // Reduce: sum of all ranks' accumulators into `root` (mcrt_reduce, RCCL; every rank calls it from its own thread).
+    // AddAccumulatorOf: this += other's accumulator, for contexts that share this GPU (no communicator needed).
+    // Both leave camera.pixels' sample count to the caller: SetSampleCount tells Resolve what the sums now hold.
+    bool Reduce(Camera& camera, void* ncclComm, int root);
+    bool AddAccumulatorOf(Camera& camera, Scene& other);
+    void SetSampleCount(Camera& camera, uint64_t samples) { camera.pixels.rays = samples; }
 
     virtual void MoveCameraToRecommendedPosition(Camera& camera);
 };

@@ -200,6 +200,89 @@ static inline float pm_acosf(float xf)
     }
 }
 
+/* exp / log / pow in double for the resolve step (source/main.cpp:150-161), fixed operation order (the classic
+ * fdlibm argument reductions and minimax sets for log on [sqrt(2)/2, sqrt(2)) and exp on [-ln2/2, ln2/2]).  The
+ * results are within 1 ulp (exp, log) and within ~1e-13 relative (pow = exp(y * log x)) of libm's: far more than the
+ * 8-bit store needs - a byte differs from libm's only where 255 * pow lies within 1e-13 of an integer. */
+static inline uint64_t pm_bits(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
+static inline double pm_from_bits(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
+static inline double pm_log(double x)      /* finite x > 0 */
+{
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10,
+                 LG1 = 6.666666666666735130e-01, LG2 = 3.999999999940941908e-01, LG3 = 2.857142874366239149e-01,
+                 LG4 = 2.222219843214978396e-01, LG5 = 1.818357216161805012e-01, LG6 = 1.531383769920937332e-01,
+                 LG7 = 1.479819860511658591e-01;
+    int64_t k = 0;
+    uint64_t u = pm_bits(x);
+    if (u < 0x0010000000000000ull) { x = x * 18014398509481984.0; u = pm_bits(x); k = -54; }     /* subnormal: scale by 2^54 */
+    k += (int64_t)(u >> 52) - 1023;
+    uint64_t m = u & 0x000FFFFFFFFFFFFFull;
+    if (m >= 0x0006A09E667F3BCDull) { k += 1; m |= 0x3FE0000000000000ull; }                      /* mantissa in [sqrt(2)/2, 1) */
+    else m |= 0x3FF0000000000000ull;                                                              /* mantissa in [1, sqrt(2)) */
+    const double f = pm_from_bits(m) - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    double t1 = LG4 + w * LG6;
+    t1 = LG2 + w * t1;
+    t1 = w * t1;
+    double t2 = LG5 + w * LG7;
+    t2 = LG3 + w * t2;
+    t2 = LG1 + w * t2;
+    t2 = z * t2;
+    const double R = t2 + t1;
+    const double hfsq = (0.5 * f) * f;
+    const double dk = (double)k;
+    return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+}
+static inline double pm_exp(double x)      /* any x */
+{
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10, INV_LN2 = 1.44269504088896338700e+00,
+                 P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 7.09782712893383973096e+02) return pm_from_bits(0x7FF0000000000000ull);
+    if (x < -7.45133219101941108420e+02) return 0.0;
+    const int64_t k = (int64_t)(INV_LN2 * x + (x < 0.0 ? -0.5 : 0.5));
+    const double t = (double)k;
+    const double hi = x - t * LN2_HI;
+    const double lo = t * LN2_LO;
+    const double r = hi - lo;
+    const double tt = r * r;
+    double p = P4 + tt * P5;
+    p = P3 + tt * p;
+    p = P2 + tt * p;
+    p = P1 + tt * p;
+    const double c = r - tt * p;
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    /* y * 2^k: y is in [0.5, 2) */
+    if (k >= -1021 && k <= 1022) return pm_from_bits(pm_bits(y) + ((uint64_t)k << 52));
+    if (k > 1022) return pm_from_bits(pm_bits(y) + ((uint64_t)(k - 2) << 52)) * 4.0;
+    return pm_from_bits(pm_bits(y) + ((uint64_t)(k + 1000) << 52)) * 9.33263618503218878990e-302;   /* 2^-1000 */
+}
+/* pow(x, y) for the tonemap: y = 1 / gamma.  Special cases as libm's pow: x^1 = x exactly, NaN in -> NaN, a negative base
+ * with a non-integer exponent -> NaN (which std::min(1.0, c) then turns into 1.0, source/opengl/data.cpp:46). */
+static inline double pm_pow(double x, double y)
+{
+    if (y == 1.0) return x;
+    if (y == 0.0) return 1.0;
+    if (x != x || y != y) return x + y;
+    double sign = 1.0;
+    if (x < 0.0) {
+        if (y != floor(y)) return (x - x) / (x - x);
+        if (fabs(y) < 9007199254740992.0 && floor(y * 0.5) * 2.0 != y) sign = -1.0;
+        x = -x;
+    }
+    if (x == 0.0) return y > 0.0 ? 0.0 * sign : pm_from_bits(0x7FF0000000000000ull) * sign;
+    if (x > 1.79769313486231570815e+308) return y > 0.0 ? x * sign : 0.0 * sign;
+    return sign * pm_exp(y * pm_log(x));
+}
+
+ORC_EXPORT void orc_portable_exp_log_pow(int which, uint64_t n, const double* a, const double* b, double* out)
+{
+    for (uint64_t i = 0; i < n; ++i) out[i] = which == 0 ? pm_exp(a[i]) : which == 1 ? pm_log(a[i]) : pm_pow(a[i], b[i]);
+}
+
 typedef struct { float (*sinf_)(float); float (*cosf_)(float); float (*tanf_)(float); float (*acosf_)(float); } mathfn;
 static const mathfn MATH_LIBM = { sinf, cosf, tanf, acosf };
 static const mathfn MATH_PORTABLE = { pm_sinf, pm_cosf, pm_tanf, pm_acosf };
@@ -1029,8 +1112,9 @@ ORC_EXPORT void orc_render_unlit(const orc_scene* S, const mcrt_camera* cam, dou
 
 /* Mean + tonemap + 8-bit BGRA store: source/main.cpp:142-164,
  * GLImageBuffer::SetPixel source/opengl/data.cpp:28-50. */
-ORC_EXPORT void orc_resolve(uint64_t npix, const double* sums, uint64_t spp, int tonemap, double gamma, double exposure, uint8_t* out_bgra,
-                            double* out_mean)
+/* portable_math != 0: pow / exp through the fixed-order pm_pow / pm_exp (what k_resolve runs), else libm like the reference. */
+ORC_EXPORT void orc_resolve_ex(uint64_t npix, const double* sums, uint64_t spp, int tonemap, double gamma, double exposure, int portable_math,
+                               uint8_t* out_bgra, double* out_mean)
 {
     for (uint64_t p = 0; p < npix; ++p) {
         double c[3];
@@ -1039,10 +1123,10 @@ ORC_EXPORT void orc_resolve(uint64_t npix, const double* sums, uint64_t spp, int
             if (out_mean) out_mean[3 * p + k] = c[k];
             if (tonemap == MCRT_TONEMAP_REINHARD) {
                 c[k] = c[k] / (c[k] + 1.0);
-                c[k] = pow(c[k], 1.0 / gamma);
+                c[k] = portable_math ? pm_pow(c[k], 1.0 / gamma) : pow(c[k], 1.0 / gamma);
             } else if (tonemap == MCRT_TONEMAP_EXPOSURE) {
-                c[k] = 1.0 - exp(-c[k] * exposure);
-                c[k] = pow(c[k], 1.0 / gamma);
+                c[k] = 1.0 - (portable_math ? pm_exp(-c[k] * exposure) : exp(-c[k] * exposure));
+                c[k] = portable_math ? pm_pow(c[k], 1.0 / gamma) : pow(c[k], 1.0 / gamma);
             }
             double t = (c[k] < 1.0) ? c[k] : 1.0;    /* std::min(1.0, c) */
             t = (t < 0.0) ? 0.0 : t;                 /* std::max(t, 0.0) */
@@ -1055,6 +1139,12 @@ ORC_EXPORT void orc_resolve(uint64_t npix, const double* sums, uint64_t spp, int
             out_bgra[4 * p + 3] = (uint8_t)(1.0 * 255.0);
         }
     }
+}
+
+ORC_EXPORT void orc_resolve(uint64_t npix, const double* sums, uint64_t spp, int tonemap, double gamma, double exposure, uint8_t* out_bgra,
+                            double* out_mean)
+{
+    orc_resolve_ex(npix, sums, spp, tonemap, gamma, exposure, 0, out_bgra, out_mean);
 }
 
 ORC_EXPORT uint32_t orc_abi_sizes(uint32_t out[4])

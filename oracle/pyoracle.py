@@ -275,12 +275,22 @@ class Oracle:
         self.lib.orc_render_unlit(C.c_void_p(scene.h), C.byref(cam), _p(out, C.c_double))
         return out
 
-    def resolve(self, sums, spp, tonemap, gamma=2.2, exposure=1.0):
+    def resolve(self, sums, spp, tonemap, gamma=2.2, exposure=1.0, portable_math=False):
+        """portable_math: pow / exp through the fixed-order kernels k_resolve runs (byte-exact against the GPU)."""
         sums = np.ascontiguousarray(sums, np.float64)
         npix = sums.size // 3
         bgra = np.zeros((npix, 4), np.uint8); mean = np.zeros((npix, 3), np.float64)
-        self.lib.orc_resolve(C.c_uint64(npix), _p(sums, C.c_double), C.c_uint64(spp), C.c_int(tonemap), C.c_double(gamma), C.c_double(exposure), _p(bgra, C.c_uint8), _p(mean, C.c_double))
+        self.lib.orc_resolve_ex(C.c_uint64(npix), _p(sums, C.c_double), C.c_uint64(spp), C.c_int(tonemap), C.c_double(gamma), C.c_double(exposure),
+                                C.c_int(1 if portable_math else 0), _p(bgra, C.c_uint8), _p(mean, C.c_double))
         return bgra, mean
+
+    def portable_exp_log_pow(self, which, a, b=None):
+        """pm_exp (0) / pm_log (1) / pm_pow (2) of the oracle, elementwise on doubles."""
+        a = np.ascontiguousarray(a, np.float64)
+        b = np.ascontiguousarray(a if b is None else b, np.float64)
+        out = np.empty_like(a)
+        self.lib.orc_portable_exp_log_pow(C.c_int(which), C.c_uint64(a.size), _p(a, C.c_double), _p(b, C.c_double), _p(out, C.c_double))
+        return out
 
 
 class _Handle:

@@ -1,0 +1,275 @@
+"""GPU tests of what sits around the hot kernel: the resolve step against the reference's bytes, the dropped-sample
+counter, the multi-GPU reduction entry points (several contexts on the one GPU of the test box; RCCL with a one-rank
+communicator), the headless driver's modes against the ORACLE (not against the library itself), and the image sizes
+that take the automatic one-lane-per-pixel path (3840x2160 and 2048x2048).
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x5EED0001
+EXE = os.path.join(ROOT, "monte-carlo-ray-tracer_amd", "mcrt_render")
+POS, TGT = (0, 0, 5), (0, 0, 0)
+
+
+def _run(args, timeout=300):
+    r = subprocess.run([EXE] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def test_resolve_bytes_equal_reference_fixture(backend, pkg, scene_of, golden):
+    """tests/golden/tonemap.npz (sums -> mean -> BGRA8 as the reference's own main.cpp:142-164 + data.cpp:28-50 produced them)
+    through mcrt_write_accumulator -> mcrt_resolve: every byte and every mean equal."""
+    g = golden("tonemap.npz")
+    spp = int(g["spp"])
+    n = len(g["sums"])
+    w = 89
+    assert n % w == 0
+    backend.upload_scene(scene_of("cornell"))
+    backend.set_camera(pkg.host_camera(w, n // w, 90.0, POS, TGT))
+    backend.write_accumulator(g["sums"])
+    for name, mode, kw in (("reinhard", pkg.TONEMAP_REINHARD, {}), ("exposure", pkg.TONEMAP_EXPOSURE, {"exposure": 1.0}),
+                           ("exposure_g18_e035", pkg.TONEMAP_EXPOSURE, {"gamma": 1.8, "exposure": 0.35}), ("none", pkg.TONEMAP_NONE, {})):
+        bgra, mean = backend.resolve(mode, spp, **kw)
+        assert np.array_equal(bgra.reshape(-1, 4), g[name]), name
+        assert np.array_equal(mean.reshape(-1, 3), g["mean"])
+
+
+def test_resolve_edge_values(backend, pkg, oracle, scene_of):
+    """Negative means (pow of a negative base: NaN -> 255, as std::min(1.0, NaN) gives), zero, huge, tiny and NaN sums:
+    bytes equal the oracle's fixed-order path AND the libm path."""
+    rng = np.random.default_rng(8)
+    vals = np.concatenate([[0.0, -0.0, -1e-3, -0.5, -2.0, 1e-300, 1e-12, 1.0, 1e6, 1e300, np.inf, np.nan, 0.5, 254.999 / 255, 3.0],
+                           rng.uniform(-1, 4, 4000 - 15), np.exp(rng.uniform(-30, 10, 2000))])
+    sums = np.resize(vals, (40 * 50, 3)) * 4.0
+    backend.upload_scene(scene_of("cornell"))
+    backend.set_camera(pkg.host_camera(50, 40, 90.0, POS, TGT))
+    backend.write_accumulator(sums)
+    for mode, kw in ((pkg.TONEMAP_REINHARD, {}), (pkg.TONEMAP_EXPOSURE, {"exposure": 0.7, "gamma": 1.8}), (pkg.TONEMAP_EXPOSURE, {"gamma": 1.0}), (pkg.TONEMAP_NONE, {})):
+        bgra, _ = backend.resolve(mode, 4, **kw)
+        with np.errstate(all="ignore"):
+            want, _ = oracle.resolve(sums, 4, mode, portable_math=True, **kw)
+            libm, _ = oracle.resolve(sums, 4, mode, **kw)
+        assert np.array_equal(bgra.reshape(-1, 4), want)
+        assert np.array_equal(want, libm)
+
+
+def test_dropped_samples_are_counted(backend, pkg, oracle, scene_of):
+    """Non-finite samples are dropped (stated deviation) and COUNTED: an infinite emission makes every
+    lit sample non-finite; the count equals the oracle's, accumulates over passes and is reset by mcrt_clear."""
+    flat = scene_of("cornell")
+    bad = pkg.FlatScene(flat.objects.copy(), flat.triangles.copy(), flat.background)
+    bad.objects["material"]["emission"][10] = np.inf
+    backend.upload_scene(bad)
+    cam = oracle.camera(48, 32, 90.0, POS, TGT)
+    backend.set_camera(cam)
+    backend.clear()
+    assert backend.dropped_samples() == 0
+    backend.render(0, 6, 100, SEED)
+    got = backend.read_accumulator()
+    want, dropped = oracle.render(oracle.scene(bad), cam, 0, 6, 100, SEED, threads=4, portable_math=True, forward_sum=True, lanes_per_pixel=backend.lanes_per_pixel(6))
+    assert dropped > 1000 and backend.dropped_samples() == dropped
+    assert np.isfinite(got).all() and np.array_equal(got, want)
+    backend.render(6, 6, 100, SEED)
+    _, more = oracle.render(oracle.scene(bad), cam, 6, 6, 100, SEED, threads=4, portable_math=True, forward_sum=True, lanes_per_pixel=backend.lanes_per_pixel(6))
+    assert backend.dropped_samples() == dropped + more
+    backend.clear()
+    assert backend.dropped_samples() == 0
+    backend.upload_scene(flat)
+
+
+def test_set_camera_clears_a_bound_accumulator(backend, pkg, scene_of):
+    """mcrt_set_camera zeroes the accumulator IN USE (a caller-bound one too); a size change returns to the context's own."""
+    import torch
+
+    backend.upload_scene(scene_of("cornell"))
+    cam = pkg.host_camera(40, 24, 90.0, POS, TGT)
+    backend.set_camera(cam)
+    own = backend.accumulator_address()
+    buf = torch.full((40 * 24 * 3,), 7.0, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    backend.bind_accumulator(buf.data_ptr())
+    backend.set_camera(cam)                                   # same size: binding kept, buffer cleared
+    backend.synchronize()
+    assert backend.accumulator_address() == buf.data_ptr() and float(buf.abs().max()) == 0.0
+    backend.render(0, 2, 100, SEED)
+    backend.synchronize()
+    assert float(buf.abs().max()) > 0.0
+    backend.set_camera(pkg.host_camera(32, 24, 90.0, POS, TGT))   # other size: the bound buffer no longer fits
+    assert backend.accumulator_address() != buf.data_ptr()
+    backend.bind_accumulator(0)
+    del buf, own
+
+
+def test_two_contexts_on_one_gpu_add_up_to_the_whole_render(backend, pkg, oracle, scene_of):
+    """SURVEY.md 8e on one GPU: two contexts render sample ranges [0, s) and [s, 2s) of every pixel, one adds the
+    other's accumulator (mcrt_add_accumulator) - the result equals the oracle's render of [0, 2s) to summation order,
+    and a one-rank RCCL communicator takes mcrt_reduce through librccl."""
+    flat = scene_of("config2")
+    cam = oracle.camera(96, 64, 90.0, POS, TGT)
+    s = 12
+    other = pkg.Backend(0)
+    try:
+        for b in (backend, other):
+            b.upload_scene(flat)
+            b.set_camera(cam)
+            b.clear()
+        backend.render(0, s, 100, SEED)
+        other.render(s, s, 100, SEED)
+        other.synchronize()
+        part = backend.read_accumulator()
+        backend.add_accumulator(other.accumulator_address())
+        got = backend.read_accumulator()
+        assert np.array_equal(got, part + other.read_accumulator())           # a plain per-value add
+        want, _ = oracle.render(oracle.scene(flat), cam, 0, 2 * s, 100, SEED, threads=8, portable_math=True, forward_sum=True)
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+        comms = pkg.comm_init_all([0])
+        try:
+            backend.reduce(comms[0], 0)                                         # ncclReduce over a world of one: the sums stay
+            backend.synchronize()
+            assert np.array_equal(backend.read_accumulator(), got)
+        finally:
+            pkg.comm_destroy(comms[0])
+    finally:
+        other.close()
+
+
+def test_driver_raw_output_equals_the_oracle(oracle, pkg, scene_of, tmp_path):
+    """mcrt_render (CornellBoxScene of the host mirror -> Scene::Render in passes -> --raw) against oracle.render on the
+    reference's dumped scene: bit-exact, pass by pass in the same slice order."""
+    raw = tmp_path / "o.f64"
+    _run(["--width", 96, "--height", 72, "--spp", 12, "--pass", 5, "--out", tmp_path / "o.ppm", "--raw", raw])
+    flat = scene_of("cornell")
+    cam = oracle.camera(96, 72, 90.0, POS, TGT)
+    sc = oracle.scene(flat)
+    want = None
+    for b, n in ((0, 5), (5, 5), (10, 2)):
+        want, _ = oracle.render(sc, cam, b, n, 100, SEED, threads=8, portable_math=True, forward_sum=True, sums=want, lanes_per_pixel=pkg.lanes_per_pixel(96, 72, n))
+    got = np.fromfile(raw, np.float64).reshape(72, 96, 3)
+    assert np.array_equal(got, want)
+    data = open(tmp_path / "o.ppm", "rb").read()
+    head = b"P6\n96 72\n255\n"
+    bgra, _ = oracle.resolve(want, 12, pkg.TONEMAP_REINHARD, portable_math=True)
+    assert np.array_equal(np.frombuffer(data[len(head):], np.uint8).reshape(-1, 3), bgra[:, 2::-1])
+
+
+def test_driver_devices_list_splits_the_samples(oracle, pkg, scene_of, tmp_path):
+    """mcrt_render --devices 0,0,0: three contexts (here on one GPU), every pass window split into contiguous sample ranges,
+    summed into the first context - equals the oracle's single render to summation order and the one-device run to 1e-12."""
+    a, b = tmp_path / "a.f64", tmp_path / "b.f64"
+    common = ["--width", 80, "--height", 48, "--spp", 20, "--pass", 8, "--out", tmp_path / "o.ppm"]
+    out = _run(common + ["--devices", "0,0,0", "--raw", a])
+    assert "3 device(s)" in out
+    _run(common + ["--raw", b])
+    multi, single = np.fromfile(a, np.float64), np.fromfile(b, np.float64)
+    assert np.allclose(multi, single, rtol=1e-12, atol=1e-12)
+    cam = oracle.camera(80, 48, 90.0, POS, TGT)
+    want, _ = oracle.render(oracle.scene(scene_of("cornell")), cam, 0, 20, 100, SEED, threads=8, portable_math=True, forward_sum=True)
+    assert np.allclose(multi.reshape(48, 80, 3), want, rtol=1e-12, atol=1e-12)
+    bad = subprocess.run([EXE, "--devices", "0,0,1", "--width", "16", "--height", "16", "--spp", "2", "--out", str(tmp_path / "p.ppm")], capture_output=True, timeout=120)
+    assert bad.returncode == 2
+
+
+def test_driver_random_pixel_mode(oracle, po, pkg, scene_of, tmp_path):
+    """RAY_TRACE_RANDOM (source/main.cpp:70-86): the picks are drawn with the reference's arithmetic from the driver's
+    generator; a pixel's k-th pick is its sample k; sums equal the oracle's per-sample radiance added in pick order."""
+    w, h, n, pick = 40, 30, 20000, 77
+    raw = tmp_path / "r.f64"
+    _run(["--width", w, "--height", h, "--random-pixels", n, "--pick-seed", pick, "--out", tmp_path / "r.ppm", "--raw", raw])
+    d = oracle.rng_doubles(pick, pick ^ 0x9E3779B97F4A7C15, 2 * n)
+    f = d.astype(np.float32)
+    xs = np.minimum((np.float32(0.0) + (np.float32(w) - np.float32(0.0)) * f[0::2]).astype(np.uint32), w - 1)
+    ys = np.minimum((np.float32(0.0) + (np.float32(h) - np.float32(0.0)) * f[1::2]).astype(np.uint32), h - 1)
+    pixels = (ys * w + xs).astype(np.uint32)
+    samples = np.zeros(n, np.uint32)
+    seen = np.zeros(w * h, np.uint32)
+    for i, p in enumerate(pixels):
+        samples[i] = seen[p]; seen[p] += 1
+    cam = oracle.camera(w, h, 90.0, POS, TGT)
+    rad = oracle.trace_samples(oracle.scene(scene_of("cornell")), cam, pixels, samples, SEED, 100, portable_math=True, forward_sum=True)
+    want = np.zeros((w * h, 3))
+    for i, p in enumerate(pixels):
+        if np.isfinite(rad[i]).all():
+            want[p] += rad[i]
+    got = np.fromfile(raw, np.float64).reshape(-1, 3)
+    assert np.array_equal(got, want)
+    assert seen.max() > seen.min()                    # ray counts really differ between pixels
+    # the image: every pixel over its own count
+    mean = want / np.maximum(seen, 1)[:, None]
+    bgra, _ = oracle.resolve(mean, 1, pkg.TONEMAP_REINHARD, portable_math=True)
+    data = open(tmp_path / "r.ppm", "rb").read()
+    head = f"P6\n{w} {h}\n255\n".encode()
+    assert np.array_equal(np.frombuffer(data[len(head):], np.uint8).reshape(-1, 3), bgra[:, 2::-1])
+
+
+def _check_pixels(backend, oracle, sc, cam, spp, acc, pixels):
+    for p in pixels:
+        s = oracle.trace_samples(sc, cam, np.full(spp, p, np.uint32), np.arange(spp, dtype=np.uint32), SEED, 100, portable_math=True, forward_sum=True)
+        tot = np.zeros(3)
+        for row in s:
+            tot = tot + row
+        assert np.array_equal(tot, acc.reshape(-1, 3)[p]), p
+
+
+def test_4k_image_takes_the_one_lane_per_pixel_path(backend, pkg, oracle, scene_of):
+    """One progressive pass of BASELINE config 5's image size (3840x2160, 8.3 M pixels >= 2^22: one lane owns a pixel, the
+    reference's summation order): sample count, determinism, random pixels against the oracle bit for bit."""
+    flat = scene_of("cornell")
+    backend.upload_scene(flat)
+    cam = oracle.camera(3840, 2160, 90.0, POS, TGT)
+    backend.set_camera(cam)
+    spp = 8
+    assert backend.lanes_per_pixel(spp) == 1
+    backend.set_counting(True)
+    backend.clear(); backend.render(0, spp, 100, SEED)
+    cnt = backend.counters()
+    backend.set_counting(False)
+    assert cnt["samples"] == 3840 * 2160 * spp
+    backend.clear(); backend.render(0, spp, 100, SEED)
+    a = backend.read_accumulator()
+    backend.clear(); backend.render(0, spp, 100, SEED)
+    assert np.array_equal(a, backend.read_accumulator())
+    assert np.isfinite(a).all()
+    assert 0.3 < a.mean() / spp < 1.5
+    rng = np.random.default_rng(12)
+    px = np.concatenate([rng.integers(0, 3840 * 2160, 6), [0, 3840 * 2160 - 1]]).astype(np.uint32)
+    _check_pixels(backend, oracle, oracle.scene(flat), cam, spp, a, px)
+    backend.set_camera(oracle.camera(64, 64, 90.0, POS, TGT))            # give the 199 MB accumulator back
+
+
+def test_config4_image_size_on_the_million_triangle_scene(backend, pkg, oracle, scene_of):
+    """BASELINE config 4's image (2048x2048 = 2^22 pixels: one lane per pixel, free-running lanes over the HBM-resident octree)
+    on the 1,000,012-triangle scene: sample count, determinism, random pixels against the oracle bit for bit."""
+    from mcrt_amd import scenes
+
+    flat = scenes.config4(scene_of("cornell"), n=1_000_000, seed=42)
+    backend.upload_scene(flat)
+    cam = oracle.camera(2048, 2048, 90.0, POS, TGT)
+    backend.set_camera(cam)
+    spp = 8
+    assert backend.lanes_per_pixel(spp) == 1
+    backend.set_counting(True)
+    backend.clear(); backend.render(0, spp, 100, SEED)
+    cnt = backend.counters()
+    backend.set_counting(False)
+    assert cnt["samples"] == 2048 * 2048 * spp
+    backend.clear(); backend.render(0, spp, 100, SEED)
+    a = backend.read_accumulator()
+    backend.clear(); backend.render(0, spp, 100, SEED)
+    assert np.array_equal(a, backend.read_accumulator())
+    assert np.isfinite(a).all() and a.mean() > 0
+    sc = oracle.scene(flat)
+    _, box, words, refs = pkg.build_scene_image(flat)
+    oracle.attach_octree(sc, box, words, refs)                           # the oracle walks the same flat octree (brute force: 10^6 tests per ray)
+    rng = np.random.default_rng(13)
+    px = np.concatenate([rng.integers(0, 2048 * 2048, 6), [1024 * 2048 + 1024, 1023 * 2048 + 1024]]).astype(np.uint32)   # + the pixels around the image centre
+    _check_pixels(backend, oracle, sc, cam, spp, a, px)
+    backend.upload_scene(scene_of("cornell"))
+    backend.set_camera(oracle.camera(64, 64, 90.0, POS, TGT))

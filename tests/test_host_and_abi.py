@@ -58,6 +58,48 @@ def test_host_camera_matches_reference(pkg, golden, tag):
     assert bytes(cam) == g["camera"].tobytes()
 
 
+@pytest.mark.parametrize("tag", ["512", "4k", "640x480", "oblique", "hexagon"])
+def test_host_get_pixel_ray_matches_reference(host, golden, tag):
+    """Camera::GetPixelRay of the host mirror (source/core/camera.h:36-57) against the rays the reference's own
+    Camera produced: origins equal, directions bit-identical."""
+    g = golden(f"camera_{tag}.npz")
+    a = g["args"]
+    n = len(g["xs"])
+    xs, ys = np.ascontiguousarray(g["xs"], np.float32), np.ascontiguousarray(g["ys"], np.float32)
+    o, d = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    fp = lambda arr: arr.ctypes.data_as(C.POINTER(C.c_float))
+    host.mcrt_host_camera_rays(C.c_uint(int(a[0])), C.c_uint(int(a[1])), C.c_float(float(a[2])), f3(a[3:6]), f3(a[6:9]), f3(a[9:12]), C.c_uint64(n),
+                               fp(xs), fp(ys), fp(o), fp(d))
+    assert np.array_equal(o, g["origins"])
+    assert np.array_equal(d.view(np.uint32), g["dirs"].view(np.uint32))
+
+
+def test_host_pixel_buffer_accumulate(host):
+    """PixelBuffer::Accumulate / GetPixelColor / GetRayCount (source/core/pixelbuffer.cpp:39-62): sums in call order, one count per call."""
+    rng = np.random.default_rng(2)
+    w, h, n = 7, 5, 400
+    xs = rng.integers(0, w, n).astype(np.uint32); ys = rng.integers(0, h, n).astype(np.uint32)
+    col = rng.normal(size=(n, 3))
+    sums, counts = np.zeros((h, w, 3)), np.zeros((h, w), np.uint64)
+    host.mcrt_host_accumulate(C.c_uint(w), C.c_uint(h), C.c_uint64(n), xs.ctypes.data_as(C.POINTER(C.c_uint32)), ys.ctypes.data_as(C.POINTER(C.c_uint32)),
+                              col.ctypes.data_as(C.POINTER(C.c_double)), sums.ctypes.data_as(C.POINTER(C.c_double)), counts.ctypes.data_as(C.POINTER(C.c_uint64)))
+    want, wcount = np.zeros((h, w, 3)), np.zeros((h, w), np.uint64)
+    for i in range(n):
+        want[ys[i], xs[i]] += col[i]
+        wcount[ys[i], xs[i]] += 1
+    assert np.array_equal(sums, want) and np.array_equal(counts, wcount)
+
+
+def test_host_generator_draws_match_reference_known_answers(host, golden):
+    """UniformRandomGenerator::RandomDouble / RandomFloat of the host mirror: the reference's known answers (fixture F1)."""
+    g = golden("rng.npz")
+    n = len(g["doubles"])
+    out = np.zeros(n)
+    host.mcrt_host_rng_doubles(C.c_uint64(int(g["seed"][0])), C.c_uint64(int(g["seed"][1])), C.c_uint64(n), out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert np.array_equal(out, g["doubles"])
+
+
 # ------------------------------------------------------------------ host C++ scene API
 @pytest.fixture(scope="module")
 def host():
@@ -254,6 +296,26 @@ def test_portable_trig_within_one_ulp_of_libm(oracle):
     xt = rng.uniform(0, np.pi, 200000).astype(np.float32)
     got, want = oracle.portable_math("tan", xt), np.tan(xt.astype(np.float64)).astype(np.float32)
     assert _ulps(got, want).max() <= 1
+
+
+def test_portable_exp_log_pow(oracle):
+    """The resolve step's pm_exp / pm_log / pm_pow: within 1 ulp of libm (exp, log), pow within 1e-14 relative, libm's special
+    cases, and no 8-bit value of a gamma curve differs from libm's on a million inputs."""
+    rng = np.random.default_rng(4)
+    x = np.concatenate([rng.uniform(-745, 709, 400_000), rng.uniform(-1, 1, 200_000), [0.0, -0.0, 709.78, -745.13, -744.9, -708.5]])
+    e, r = oracle.portable_exp_log_pow(0, x), np.exp(x)
+    assert (np.abs(e - r) <= np.spacing(np.maximum(r, 5e-324))).all()
+    x = np.concatenate([np.exp(rng.uniform(-740, 709, 400_000)), rng.uniform(0.5, 2, 200_000), [1.0, 5e-324, 1e-310, 1.79e308, 2.0, 0.5]])
+    l, r = oracle.portable_exp_log_pow(1, x), np.log(x)
+    assert (np.abs(l - r) <= np.spacing(np.abs(r))).all()
+    x = rng.uniform(0, 1, 1_000_000)
+    for inv_gamma in (1 / 2.2, 1 / 1.8, 0.5):
+        p, r = oracle.portable_exp_log_pow(2, x, np.full_like(x, inv_gamma)), np.power(x, inv_gamma)
+        assert np.max(np.abs(p - r) / r) < 1e-14
+        assert np.array_equal((p * 255.0).astype(np.uint8), (r * 255.0).astype(np.uint8))
+    with np.errstate(invalid="ignore"):
+        sp = oracle.portable_exp_log_pow(2, np.array([-0.5, 0.0, 1.0, np.nan, -2.0, -2.0, np.inf, 0.3, 0.3]), np.array([0.45, 0.45, 0.45, 0.45, 2.0, 3.0, 0.45, 1.0, 0.0]))
+    assert np.isnan(sp[0]) and sp[1] == 0.0 and sp[2] == 1.0 and np.isnan(sp[3]) and abs(sp[4] - 4.0) < 1e-14 and abs(sp[5] + 8.0) < 1e-14 and np.isinf(sp[6]) and sp[7] == 0.3 and sp[8] == 1.0
 
 
 def test_oracle_modes_agree(oracle, pkg, scene_of, golden):

@@ -112,6 +112,10 @@ def test_tonemap_table(oracle, pkg, golden):
     assert np.array_equal(oracle.resolve(g["sums"], spp, pkg.abi.TONEMAP_EXPOSURE, exposure=1.0)[0], g["exposure"])
     assert np.array_equal(oracle.resolve(g["sums"], spp, pkg.abi.TONEMAP_EXPOSURE, gamma=1.8, exposure=0.35)[0], g["exposure_g18_e035"])
     assert np.array_equal(oracle.resolve(g["sums"], spp, pkg.abi.TONEMAP_NONE)[0], g["none"])
+    # the fixed-order pow / exp that k_resolve runs give the reference's bytes too
+    for name, mode, kw in (("reinhard", pkg.abi.TONEMAP_REINHARD, {}), ("exposure", pkg.abi.TONEMAP_EXPOSURE, {"exposure": 1.0}),
+                           ("exposure_g18_e035", pkg.abi.TONEMAP_EXPOSURE, {"gamma": 1.8, "exposure": 0.35}), ("none", pkg.abi.TONEMAP_NONE, {})):
+        assert np.array_equal(oracle.resolve(g["sums"], spp, mode, portable_math=True, **kw)[0], g[name]), name
 
 
 def test_oracle_against_live_reference(oracle, ref, scene_of):
