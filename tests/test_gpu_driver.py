@@ -86,26 +86,29 @@ def test_dropped_samples_are_counted(backend, pkg, oracle, scene_of):
 
 
 def test_set_camera_clears_a_bound_accumulator(backend, pkg, scene_of):
-    """mcrt_set_camera zeroes the accumulator IN USE (a caller-bound one too); a size change returns to the context's own."""
-    import torch
-
+    """mcrt_set_camera zeroes the accumulator IN USE (a caller-bound one too); a size change returns to the context's own.
+    The caller-owned device buffer here is the accumulator of a second context."""
     backend.upload_scene(scene_of("cornell"))
     cam = pkg.host_camera(40, 24, 90.0, POS, TGT)
     backend.set_camera(cam)
-    own = backend.accumulator_address()
-    buf = torch.full((40 * 24 * 3,), 7.0, dtype=torch.float64, device="cuda")
-    torch.cuda.synchronize()
-    backend.bind_accumulator(buf.data_ptr())
-    backend.set_camera(cam)                                   # same size: binding kept, buffer cleared
-    backend.synchronize()
-    assert backend.accumulator_address() == buf.data_ptr() and float(buf.abs().max()) == 0.0
-    backend.render(0, 2, 100, SEED)
-    backend.synchronize()
-    assert float(buf.abs().max()) > 0.0
-    backend.set_camera(pkg.host_camera(32, 24, 90.0, POS, TGT))   # other size: the bound buffer no longer fits
-    assert backend.accumulator_address() != buf.data_ptr()
-    backend.bind_accumulator(0)
-    del buf, own
+    owner = pkg.Backend(0)
+    try:
+        owner.upload_scene(scene_of("cornell"))
+        owner.set_camera(cam)
+        owner.write_accumulator(np.full((24, 40, 3), 7.0))
+        buf = owner.accumulator_address()
+        backend.bind_accumulator(buf)
+        backend.set_camera(cam)                                   # same size: binding kept, buffer cleared
+        backend.synchronize()
+        assert backend.accumulator_address() == buf and np.abs(owner.read_accumulator()).max() == 0.0
+        backend.render(0, 2, 100, SEED)
+        backend.synchronize()
+        assert np.abs(owner.read_accumulator()).max() > 0.0
+        backend.set_camera(pkg.host_camera(32, 24, 90.0, POS, TGT))   # other size: the bound buffer no longer fits
+        assert backend.accumulator_address() != buf
+        backend.bind_accumulator(0)
+    finally:
+        owner.close()
 
 
 def test_two_contexts_on_one_gpu_add_up_to_the_whole_render(backend, pkg, oracle, scene_of):
