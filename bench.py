@@ -398,8 +398,8 @@ def cpu_baseline(pkg, flat, scene_name, width, height, note):
     brute_eng.render(brute_scene, bcam, 0, 1, DEPTH, SEED, threads=threads)
     brute_rate = 64 * 64 / (time.perf_counter() - t0) / 1e6
     note("config-4 CPU baseline: the restatement through the flat octree")
-    _, box, words, refs = pkg.build_scene_image(flat)
-    orc.attach_octree(scene, box, words, refs)
+    tree_info, box, words, refs = pkg.build_scene_image(flat)
+    orc.attach_octree(scene, tree_info, box, words, refs)
     cam = orc.camera(width, height, 90.0, pos, tgt)
     spp = sized_spp(orc, scene, cam, 6.0)
     med, rates = timed(orc, scene, cam, spp)

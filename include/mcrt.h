@@ -344,6 +344,9 @@ typedef struct mcrt_octree_info {
     uint32_t max_depth;
     uint32_t blob_bytes;       /* size of the packed scene image            */
     uint32_t lds_resident;     /* 1 when kernels stage the whole image in LDS */
+    float root_cell_min[3];    /* the root's cell: every node's cell follows from it by halving  */
+    float root_cell_max[3];    /* at the centre, centre = min + 0.5f * (max - min), octant bit a */
+    float pad;                 /* set = upper half on axis a; cells are entered with this padding */
 } mcrt_octree_info;
 
 int mcrt_octree_info_get(mcrt_ctx* ctx, mcrt_octree_info* out);

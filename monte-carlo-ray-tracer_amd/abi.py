@@ -90,6 +90,9 @@ class OctreeInfo(C.Structure):
         ("max_depth", C.c_uint32),
         ("blob_bytes", C.c_uint32),
         ("lds_resident", C.c_uint32),
+        ("root_cell_min", C.c_float * 3),
+        ("root_cell_max", C.c_float * 3),
+        ("pad", C.c_float),
     ]
 
 

@@ -149,7 +149,7 @@ template <> struct WalkStackFor<GlbPtr> {
     static __device__ __forceinline__ void bind(type& st, uint32_t* lds) { st.col = (__attribute__((address_space(3))) uint32_t*)lds + threadIdx.x; }
 };
 // LDS words the kernels that trace paths need after the SMALL image (octree walk over an HBM-resident image)
-constexpr uint32_t kWalkLdsWords = LDS_STACK_ENTRIES * 3 * LDS_STACK_BLOCK;
+constexpr uint32_t kWalkLdsWords = LDS_STACK_ENTRIES * 2 * LDS_STACK_BLOCK;
 static_assert(LDS_STACK_BLOCK == kBlock, "LdsStack columns are one per thread of the block");
 
 // Scheduling knobs of trace_lane (wave-uniform runtime values, so that they can be swept without rebuilding):
@@ -1595,6 +1595,8 @@ int mcrt_octree_info_get(mcrt_ctx* c, mcrt_octree_info* out)
     out->max_depth = c->flat.tree_depth;
     out->blob_bytes = (c->view.small_words + c->view.big_words) * 4;
     out->lds_resident = c->big_in_lds ? 1u : 0u;
+    for (int a = 0; a < 3; ++a) { out->root_cell_min[a] = c->flat.root_cell[a]; out->root_cell_max[a] = c->flat.root_cell[3 + a]; }
+    out->pad = c->flat.pad;
     return MCRT_OK;
 }
 
@@ -1638,6 +1640,8 @@ int mcrt_scene_image_info(const mcrt_scene_image* image, mcrt_octree_info* out)
     out->blob_bytes = (f.view.small_words + f.view.big_words) * 4;
     const size_t small_bytes = (((size_t)f.view.small_words + 3u) & ~size_t(3)) * 4;
     out->lds_resident = (small_bytes + (size_t)f.view.big_words * 4 <= kLdsBudgetBytes) ? 1u : 0u;
+    for (int a = 0; a < 3; ++a) { out->root_cell_min[a] = f.root_cell[a]; out->root_cell_max[a] = f.root_cell[3 + a]; }
+    out->pad = f.pad;
     return MCRT_OK;
 }
 

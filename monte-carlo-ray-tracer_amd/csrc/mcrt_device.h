@@ -441,60 +441,66 @@ MCRT_DEV void wave_sync()
 // Nearest hit through the flat octree.  Same result as cast_brute: the
 // candidate set is every primitive whose mesh gate passes, the winner is the
 // lexicographic minimum of (t, primitive id) - "earlier object / earlier
-// triangle wins ties", source/scene.cpp:73 and source/objects/mesh.cpp:22.
+// triangle wins ties", source/scene.cpp:73 and source/objects/mesh.cpp:22 -
+// which does not depend on the order in which candidates are met.
 // The mesh gate (source/objects/mesh.cpp:11-16) is a pure function of (ray,
 // mesh); it is evaluated the first time the ray meets a triangle of that mesh
 // and cached in two 64-bit masks.
 //
-// The walk is RESUMABLE: run() returns to the caller as soon as enough lanes of the wavefront have
-// finished their ray, the caller shades those lanes, gives them their next ray and calls run()
-// again; lanes in mid-traversal simply carry on.  Ray lengths in a big scene are close to
-// exponentially distributed, so a wavefront that waits for its slowest lane on every query runs at
-// a fraction of its width; refilling keeps it above the exit threshold.  One iteration of run() is
-// one node visit: the node's leaf records (streamed, next record requested before the current one
-// is tested), then its eight child slots fetched together (sixteen 16-byte loads in flight).
-// A stack entry is everything a visit needs (entry distance, child word, leaf-list index), copied out
-// of the child's record when the parent tested its box: a pop never re-reads the node.
+// One iteration of run() is one node visit:
+//   pop      the nearest stack entry not behind the best hit so far: (entry distance, node index);
+//   fetch    the node's 48-byte record (three 16-byte loads issued together) and test its tight box;
+//   descend  which of the node's octants does the ray pass, and where does it enter them?  That follows from the
+//            node's CELL alone - its faces and three mid planes, nine plane distances - so no child record is
+//            touched: octants are entered through cells widened by the builder's padding (a primitive is referenced
+//            from every cell that contains a point of it, so the cell that contains the hit point is always among
+//            them, rounding included), pushed far to near.  A ray passes at most four octants of a cell unless it
+//            runs within the padding of its centre; the old walk fetched and slab-tested all eight child boxes of
+//            every visited node (256 bytes and sixteen loads a visit: 2.2x the algorithmic traffic);
+//   leaves   at most `chunk` records of the node's list (streamed, the next record requested before the current one
+//            is tested); a longer list re-queues its rest on top of the stack, so that the other lanes of the
+//            wavefront wait for `chunk` records, not for the longest list among 64 nodes.
+// The walk is RESUMABLE: run() returns to the caller as soon as enough lanes of the wavefront have finished their
+// ray, the caller shades those lanes, gives them their next ray and calls run() again; lanes in mid-traversal simply
+// carry on.  Ray lengths in a big scene are close to exponentially distributed, so a wavefront that waits for its
+// slowest lane on every query runs at a fraction of its width; refilling keeps it above the exit threshold.
 struct ScratchStack {
     float t_[TRAVERSAL_STACK];
-    uint32_t cw_[TRAVERSAL_STACK], leaf_[TRAVERSAL_STACK];
-    MCRT_DEV void put(int i, float t, uint32_t cw, uint32_t leaf) { t_[i] = t; cw_[i] = cw; leaf_[i] = leaf; }
+    uint32_t w_[TRAVERSAL_STACK];
+    MCRT_DEV void put(int i, float t, uint32_t w) { t_[i] = t; w_[i] = w; }
     MCRT_DEV float t(int i) const { return t_[i]; }
-    MCRT_DEV void get(int i, uint32_t& cw, uint32_t& leaf) const { cw = cw_[i]; leaf = leaf_[i]; }
+    MCRT_DEV uint32_t get(int i) const { return w_[i]; }
 };
 // The first LDS_STACK_ENTRIES entries live in LDS (field-major, one dword column per thread of the 256-thread
 // block: bank = thread id, conflict-free whatever the lanes' stack depths), the rest in scratch memory.  Scratch
 // is dword-interleaved per wavefront, so 64 lanes pushing at 64 different depths touch 64 different cache lines:
 // measured on the 1M-triangle scene, a scratch-only stack was most of the kernel's HBM traffic.
-constexpr int LDS_STACK_ENTRIES = 12;
+constexpr int LDS_STACK_ENTRIES = 18;
 constexpr int LDS_STACK_BLOCK = 256;
 struct LdsStack {
     __attribute__((address_space(3))) uint32_t* col;      // this thread's column
     float t_[TRAVERSAL_STACK - LDS_STACK_ENTRIES];
-    uint32_t cw_[TRAVERSAL_STACK - LDS_STACK_ENTRIES], leaf_[TRAVERSAL_STACK - LDS_STACK_ENTRIES];
-    MCRT_DEV void put(int i, float t, uint32_t cw, uint32_t leaf)
+    uint32_t w_[TRAVERSAL_STACK - LDS_STACK_ENTRIES];
+    MCRT_DEV void put(int i, float t, uint32_t w)
     {
-        if (i < LDS_STACK_ENTRIES) {
-            col[(i * 3 + 0) * LDS_STACK_BLOCK] = __float_as_uint(t); col[(i * 3 + 1) * LDS_STACK_BLOCK] = cw; col[(i * 3 + 2) * LDS_STACK_BLOCK] = leaf;
-        } else { t_[i - LDS_STACK_ENTRIES] = t; cw_[i - LDS_STACK_ENTRIES] = cw; leaf_[i - LDS_STACK_ENTRIES] = leaf; }
+        if (i < LDS_STACK_ENTRIES) { col[(i * 2 + 0) * LDS_STACK_BLOCK] = __float_as_uint(t); col[(i * 2 + 1) * LDS_STACK_BLOCK] = w; }
+        else { t_[i - LDS_STACK_ENTRIES] = t; w_[i - LDS_STACK_ENTRIES] = w; }
     }
-    MCRT_DEV float t(int i) const { return i < LDS_STACK_ENTRIES ? __uint_as_float(col[(i * 3 + 0) * LDS_STACK_BLOCK]) : t_[i - LDS_STACK_ENTRIES]; }
-    MCRT_DEV void get(int i, uint32_t& cw, uint32_t& leaf) const
-    {
-        if (i < LDS_STACK_ENTRIES) { cw = col[(i * 3 + 1) * LDS_STACK_BLOCK]; leaf = col[(i * 3 + 2) * LDS_STACK_BLOCK]; }
-        else { cw = cw_[i - LDS_STACK_ENTRIES]; leaf = leaf_[i - LDS_STACK_ENTRIES]; }
-    }
+    MCRT_DEV float t(int i) const { return i < LDS_STACK_ENTRIES ? __uint_as_float(col[(i * 2 + 0) * LDS_STACK_BLOCK]) : t_[i - LDS_STACK_ENTRIES]; }
+    MCRT_DEV uint32_t get(int i) const { return i < LDS_STACK_ENTRIES ? col[(i * 2 + 1) * LDS_STACK_BLOCK] : w_[i - LDS_STACK_ENTRIES]; }
 };
 
-// Reciprocal of a direction component for the node slab tests.  A zero (or denormal) component would give
-// +-inf, and (face - origin) * inf is NaN when the origin lies exactly on a box face - min/max drop the NaN
-// and the node is culled although the ray runs inside it.  Clamped to +-FLT_MAX the product is 0 on the
-// face, +-huge off it: the slab is open for a parallel ray between the faces and closed outside them, which
-// is AABB::IntersectsRay's "skip the axis" (source/core/aabb.h:56) plus the containment the caller needs.
+// Reciprocal of a direction component for the slab and plane tests of the walk.  A zero (or tiny) component would give
+// +-inf, and (face - origin) * inf is NaN when the origin lies exactly on the face - min/max drop the NaN and the node
+// is culled although the ray runs inside it.  Clamped to +-2^100 every product of the walk stays FINITE (coordinates up
+// to 1e8): 0 on the face, +-huge off it - the slab is open for a parallel ray between the faces and closed outside them,
+// which is AABB::IntersectsRay's "skip the axis" (source/core/aabb.h:56) plus the containment the caller needs - and
+// the padding keeps its meaning for a parallel ray: pad * 2^100 is finite and compares with (plane - origin) * 2^100.
+constexpr float kWalkRcpMax = 1.2676506002282294e30f;     // 2^100
 MCRT_DEV float slab_rcp(float d)
 {
     const float r = __frcp_rn(d);
-    return fabsf(r) <= kFltMax ? r : copysignf(kFltMax, d);
+    return fabsf(r) <= kWalkRcpMax ? r : copysignf(kWalkRcpMax, d);
 }
 
 template <class PS, class PB, bool kCount> struct OctreeWalk {
@@ -505,17 +511,17 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
     MCRT_DEV bool done() const { return sp == 0; }
     MCRT_DEV void idle() { sp = 0; gate_known = gate_pass = 0; best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax; }
 
-    template <class St> MCRT_DEV void begin(PB big, const SceneView& v, St& st, Counters& cn)
+    template <class St> MCRT_DEV void begin(PB, const SceneView&, St& st, Counters& cn)
     {
         best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax;
         if (kCount) cn.rays++;
         gate_known = 0; gate_pass = 0;
-        const U4 root = ld4(big + v.off_node, 4);
-        st.put(0, 0.0f, root.z, root.w); sp = 1;
+        st.put(0, 0.0f, 0u); sp = 1;          // the root
     }
 
-    // One node visit.
-    template <class St> MCRT_DEV void visit(PS sm, PB nodes, PB leaves, const SceneView& v, St& st, V3 o, V3 d, float ix, float iy, float iz, uint32_t flip,
+    // One node visit.  inv: clamped reciprocals of the direction; padt = pad * |inv| per axis; flip: bit a set where the ray runs
+    // towards smaller coordinates on axis a (sign of inv, so that +-0 components are treated consistently).
+    template <class St> MCRT_DEV void visit(PS sm, PB nodes, PB leaves, const SceneView& v, St& st, V3 o, V3 d, V3 inv, V3 padt, uint32_t flip,
                         uint32_t chunk, Counters& cn)
     {
         // next entry that was not entered behind the best hit so far
@@ -525,16 +531,59 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
             --sp;
             t_in = st.t(sp);
         } while (t_in > best.t);
-        uint32_t cw, leaf;
-        st.get(sp, cw, leaf);
-        const bool resumed = leaf != NO_REFS && (leaf & LEAF_RESUME);
-        if (resumed) leaf &= ~LEAF_RESUME;
-        else if (kCount) cn.nodes++;
+        const uint32_t w = st.get(sp);
+        uint32_t leaf;
+        if (w & LEAF_RESUME) leaf = w & ~LEAF_RESUME;          // the rest of a list whose node was visited before
+        else {
+            const uint32_t rec = w * NODE_STRIDE;
+            const U4 ra = ld4(nodes, rec), rb = ld4(nodes, rec + 4), rc = ld4(nodes, rec + 8);
+            // all three loads in one round trip: without this the compiler sinks the third into the `mask != 0` branch, behind the tight test
+            asm volatile("" ::"v"(rc.x), "v"(rc.y), "v"(rc.z), "v"(rc.w));
+            if (kCount) cn.nodes++;
+            {
+                // the node's own tight box against [0, best.t]
+                float t0 = 0.0f, t1 = best.t;
+                float p = (__uint_as_float(ra.x) - o.x) * inv.x, q = (__uint_as_float(ra.w) - o.x) * inv.x;
+                t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
+                p = (__uint_as_float(ra.y) - o.y) * inv.y; q = (__uint_as_float(rb.x) - o.y) * inv.y;
+                t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
+                p = (__uint_as_float(ra.z) - o.z) * inv.z; q = (__uint_as_float(rb.y) - o.z) * inv.z;
+                t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
+                if (!(t0 <= t1)) return;
+            }
+            leaf = rb.w;
+            const uint32_t cw = rb.z, mask = cw >> 24;
+            if (mask) {
+                const uint32_t base = cw & 0x00FFFFFFu;
+                const float scale = __uint_as_float(rc.w);
+                // per axis: entry / exit distances of the near half [near face - pad, mid + pad] and the far half [mid - pad, far face + pad]
+                float n_in[3], n_out[3], f_in[3], f_out[3];
+                const float cmn[3] = { __uint_as_float(rc.x), __uint_as_float(rc.y), __uint_as_float(rc.z) };
+                const float oo[3] = { o.x, o.y, o.z }, ii[3] = { inv.x, inv.y, inv.z }, pp[3] = { padt.x, padt.y, padt.z };
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float size = v.root_size[a] * scale;
+                    const float mid = cmn[a] + 0.5f * size, cmx = cmn[a] + size;
+                    const bool back = (flip >> a) & 1u;
+                    const float tn = ((back ? cmx : cmn[a]) - oo[a]) * ii[a];
+                    const float tm = (mid - oo[a]) * ii[a];
+                    const float tf = ((back ? cmn[a] : cmx) - oo[a]) * ii[a];
+                    n_in[a] = tn - pp[a]; n_out[a] = tm + pp[a];
+                    f_in[a] = tm - pp[a]; f_out[a] = tf + pp[a];
+                }
+                // octants in ray order: bit a of k clear = the half the ray meets first on axis a; far octants are pushed first
+#pragma unroll
+                for (int k = 7; k >= 0; --k) {
+                    const float t0 = fmaxf(fmaxf((k & 1) ? f_in[0] : n_in[0], (k & 2) ? f_in[1] : n_in[1]), fmaxf((k & 4) ? f_in[2] : n_in[2], 0.0f));
+                    const float t1 = fminf(fminf((k & 1) ? f_out[0] : n_out[0], (k & 2) ? f_out[1] : n_out[1]), fminf((k & 4) ? f_out[2] : n_out[2], best.t));
+                    const uint32_t oct = (uint32_t)k ^ flip;
+                    if (((mask >> oct) & 1u) && t0 <= t1) { st.put(sp, t0, base + __popc(mask & ((1u << oct) - 1u))); ++sp; }
+                }
+            }
+        }
 
         if (leaf != NO_REFS) {
-            // At most `chunk` records per visit: a lane with a long list re-queues the rest of it on top of its
-            // stack (and tests the node's children after the last record), so that the other lanes of the
-            // wavefront wait for `chunk` records, not for the longest list among 64 nodes.
+            // At most `chunk` records per visit: a lane with a long list re-queues the rest of it on top of its stack.
             uint32_t r = leaf * LEAF_STRIDE;
             U4 a = ld4(leaves, r), b = ld4(leaves, r + 4), c = ld4(leaves, r + 8);
             bool finished = false;
@@ -574,46 +623,7 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
                 if (c.y & REF_LAST) { finished = true; break; }
                 a = na; b = nb; c = nc;
             }
-            if (!finished) {
-                st.put(sp, t_in, cw, (leaf + chunk) | LEAF_RESUME);
-                ++sp;
-                return;
-            }
-        }
-
-        const uint32_t mask = cw >> 24;
-        if (mask) {
-            const uint32_t base = cw & 0x00FFFFFFu;
-            // All eight octant slots are fetched unconditionally (an absent octant re-reads the first child: same
-            // cache line); far octants are pushed first so the nearest is popped first.
-            // two batches of four slots: all eight loads of a batch are issued before the first test
-#pragma unroll
-            for (int batch = 1; batch >= 0; --batch) {
-                U4 lo[4], hi[4];
-                bool exists[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t oct = (uint32_t)(batch * 4 + 3 - j) ^ flip;
-                    exists[j] = (mask >> oct) & 1u;
-                    const uint32_t child = exists[j] ? base + __popc(mask & ((1u << oct) - 1u)) : base;
-                    lo[j] = ld4(nodes, child * NODE_STRIDE);
-                    hi[j] = ld4(nodes, child * NODE_STRIDE + 4);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float t0 = 0.0f, t1 = best.t;
-                    float p = (__uint_as_float(lo[j].x) - o.x) * ix;
-                    float q = (__uint_as_float(lo[j].w) - o.x) * ix;
-                    t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
-                    p = (__uint_as_float(lo[j].y) - o.y) * iy;
-                    q = (__uint_as_float(hi[j].x) - o.y) * iy;
-                    t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
-                    p = (__uint_as_float(lo[j].z) - o.z) * iz;
-                    q = (__uint_as_float(hi[j].y) - o.z) * iz;
-                    t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
-                    if (exists[j] && t0 <= t1) { st.put(sp, t0, hi[j].z, hi[j].w); ++sp; }
-                }
-            }
+            if (!finished) { st.put(sp, t_in, (leaf + chunk) | LEAF_RESUME); ++sp; }
         }
     }
 
@@ -621,10 +631,10 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
     // return once fewer than refill/64 of the lanes that came in unfinished are still walking.
     template <class St> MCRT_DEV void run(PS sm, PB big, const SceneView& v, St& st, V3 o, V3 d, Counters& cn, uint32_t refill, uint32_t chunk = 0xFFFFFFFFu)
     {
-        // Node culling is conservative (boxes are padded at build time); reciprocals are clamped, see slab_rcp.
-        const float ix = slab_rcp(d.x), iy = slab_rcp(d.y), iz = slab_rcp(d.z);
-        // visit octants front to back: flip the octant index on axes where the ray runs backwards
-        const uint32_t flip = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+        // Node and octant culling is conservative (boxes and cells are padded); reciprocals are clamped, see slab_rcp.
+        const V3 inv = mk(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
+        const V3 padt = mk(v.walk_pad * fabsf(inv.x), v.walk_pad * fabsf(inv.y), v.walk_pad * fabsf(inv.z));
+        const uint32_t flip = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
         const PB nodes = big + v.off_node;
         const PB leaves = big + v.off_leaf;
         const uint32_t entered = (uint32_t)__popcll(__ballot(sp > 0));
@@ -632,7 +642,7 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
         for (;;) {
             const uint32_t walking = (uint32_t)__popcll(__ballot(sp > 0));
             if (walking == 0 || walking < keep) break;
-            if (sp > 0) visit(sm, nodes, leaves, v, st, o, d, ix, iy, iz, flip, chunk, cn);
+            if (sp > 0) visit(sm, nodes, leaves, v, st, o, d, inv, padt, flip, chunk, cn);
         }
     }
 };

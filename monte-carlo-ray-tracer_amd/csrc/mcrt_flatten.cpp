@@ -375,11 +375,15 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
     }
     out.tree_depth = B.deepest;
     out.ref_count = uint32_t(out.refs.size());
+    for (int a = 0; a < 3; ++a) { out.root_cell[a] = B.pool[0].cell.mn[a]; out.root_cell[3 + a] = B.pool[0].cell.mx[a]; }
+    out.pad = pad;
 
     // ---- SMALL image -----------------------------------------------------------------
     SceneView& v = out.view;
     v = SceneView{};
     v.nobj = nobj; v.nlights = uint32_t(lights.size()); v.ntri = sc->triangle_count; v.nprim = nprim; v.nnode = nnode;
+    for (int a = 0; a < 3; ++a) v.root_size[a] = B.pool[0].cell.mx[a] - B.pool[0].cell.mn[a];
+    v.walk_pad = pad;
     v.off_obj = 0;
     v.off_lights = v.off_obj + nobj * OBJ_STRIDE;
     v.off_bg = (v.off_lights + v.nlights + 1u) & ~1u;   // doubles: even word offset
@@ -447,6 +451,9 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
         for (uint32_t k = 0; k < 6; ++k) w[NODE_BOX + k] = fbits(out.node_box[size_t(f) * 6 + k]);
         w[NODE_CHILD] = out.node_words[size_t(f) * 2];
         w[NODE_LEAF] = out.node_words[size_t(f) * 2 + 1];
+        const BuildNode& bn = B.pool[size_t(order[f])];
+        for (uint32_t k = 0; k < 3; ++k) w[NODE_CELL + k] = fbits(bn.cell.mn[k]);
+        w[NODE_SCALE] = fbits(std::ldexp(1.0f, -int(bn.depth)));
     }
     for (uint32_t t = 0; t < sc->triangle_count; ++t) {
         const mcrt_triangle& tr = sc->triangles[t];

@@ -20,6 +20,8 @@ struct FlatScene {
     std::vector<float> node_box;       // node_count * 6
     std::vector<uint32_t> node_words;  // node_count * 2
     std::vector<uint32_t> refs;
+    float root_cell[6] = { 0, 0, 0, 0, 0, 0 };   // min xyz, max xyz of the root cell
+    float pad = 0.0f;
 };
 
 // Returns MCRT_OK or an MCRT_ERR_* code with `err` set.

@@ -55,15 +55,19 @@ enum : uint32_t { TRI_V0 = 0, TRI_E1 = 3, TRI_E2 = 6, TRI_N = 9, TRI_STRIDE = 12
 // copy of itself (a repeated test can never win the strict `<`).
 enum : uint32_t { PAIR_V0 = 0, PAIR_E1 = 6, PAIR_E2 = 12, PAIR_STRIDE = 20 };
 
-// ---- octree node record (BIG image), NODE_STRIDE words each, 32-byte aligned: one record is two
-// 16-byte loads and the (up to 8) children of a node are contiguous, so a node visit touches
-// 256 contiguous bytes instead of one cache line per box coordinate.
+// ---- octree node record (BIG image), NODE_STRIDE words each, 16-byte aligned: three 16-byte loads bring everything a
+// visit needs - the node's own tight box, its child word and leaf list, and its CELL (the octant it owns: min corner and
+// 2^-depth, so that cell size = root size * scale).  The children's boxes are NOT fetched to decide where a ray goes
+// next: which octants of the cell the ray passes follows from the cell's three mid planes (OctreeWalk::visit), and a
+// child's record is read only when the child is popped.
 enum : uint32_t {
     NODE_BOX = 0,        // min.xyz, max.xyz (tight, padded)
     NODE_CHILD = 6,      // bits 0..23: index of the first child (children are contiguous,
                          // only non-empty octants are stored), bits 24..31: octant mask
     NODE_LEAF = 7,       // index of this node's first leaf record, NO_REFS if none
-    NODE_STRIDE = 8
+    NODE_CELL = 8,       // min corner of the node's cell, 3 floats (the builder's own values)
+    NODE_SCALE = 11,     // 2^-depth as a float
+    NODE_STRIDE = 12
 };
 // ---- leaf record (BIG image), LEAF_STRIDE words each, 16-byte aligned.  One per (node, primitive)
 // reference, a node's records contiguous: the triangle's v0/edge1/edge2 are INLINED, so walking a
@@ -76,7 +80,7 @@ enum : uint32_t {
     LEAF_STRIDE = 12
 };
 constexpr uint32_t LEAF_SPHERE = 0x80000000u;
-constexpr uint32_t LEAF_RESUME = 0x80000000u;  // traversal stack only: the entry resumes a leaf list part-way (index in the low bits)
+constexpr uint32_t LEAF_RESUME = 0x80000000u;  // traversal stack only: the entry is not a node index but a leaf list to resume part-way (record index in the low bits)
 constexpr uint32_t NO_REFS = 0xFFFFFFFFu;
 constexpr uint32_t REF_LAST = 0x80000000u;   // set on the last reference of a node's list
 constexpr uint32_t MISS = 0xFFFFFFFFu;
@@ -95,6 +99,8 @@ struct SceneView {
     uint32_t has_pairs;          // triangle-pair records present (scan path usable)
     uint32_t tri_src;            // word offset of the triangle records in the global BIG image (== off_tri except in the
                                  // view handed to the flat-scan kernels, whose off_tri addresses their LDS copy)
+    float root_size[3];          // extent of the root cell (a node's cell size = root_size * its NODE_SCALE)
+    float walk_pad;              // the builder's padding: octants are entered through cells widened by this much
 };
 
 } // namespace mcrt

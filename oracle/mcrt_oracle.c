@@ -642,18 +642,46 @@ ORC_EXPORT void orc_intersect(const orc_scene* S, uint64_t n, const float* o, co
  * reference's brute force (10^6 triangle tests per ray) is not feasible. */
 typedef struct orc_octree {
     uint32_t node_count;
-    const float* box;        /* node_count * 6: min xyz, max xyz (padded)            */
+    const float* box;        /* node_count * 6: min xyz, max xyz (tight, padded)     */
     const uint32_t* words;   /* node_count * 2: child word (mask<<24 | first child), first prim ref */
     const uint32_t* refs;    /* primitive ids, bit 31 = last of the node's list      */
+    float root_cell[6];      /* mcrt_octree_info: root_cell_min, root_cell_max       */
+    float pad;               /* mcrt_octree_info: pad                                */
+    const float* cell;       /* node_count * 4: cell min xyz, 2^-depth (orc_octree_cells) */
 } orc_octree;
 
 typedef struct orc_octree_stats { uint64_t rays, nodes, tris, spheres, gates; } orc_octree_stats;
 
 struct orc_tree {
     orc_octree view;
-    float* box; uint32_t* words; uint32_t* refs;      /* owned copies (attach) */
+    float* box; uint32_t* words; uint32_t* refs; float* cell;   /* owned copies (attach) */
     uint32_t* first_prim; uint32_t* prim_obj;         /* primitive ids are assigned in (object, element) order */
 };
+
+/* Every node's cell from the root cell, the way the builder halves cells (csrc/mcrt_flatten.cpp: centre = min + 0.5f * (max - min),
+ * octant bit a set = upper half on axis a): the values the node records carry (NODE_CELL, NODE_SCALE). */
+ORC_EXPORT void orc_octree_cells(const orc_octree* T, float* out)
+{
+    float* mx = (float*)malloc(sizeof(float) * 3 * (size_t)T->node_count);
+    for (int a = 0; a < 3; ++a) { out[a] = T->root_cell[a]; mx[a] = T->root_cell[3 + a]; }
+    out[3] = 1.0f;
+    for (uint32_t n = 0; n < T->node_count; ++n) {      /* breadth-first order: a parent comes before its children */
+        const uint32_t cw = T->words[2 * (size_t)n], base = cw & 0x00FFFFFFu, mask = cw >> 24;
+        uint32_t rank = 0;
+        for (uint32_t c = 0; c < 8; ++c) {
+            if (!(mask & (1u << c))) continue;
+            const uint32_t ch = base + rank++;
+            for (int a = 0; a < 3; ++a) {
+                const float lo = out[4 * (size_t)n + a], hi = mx[3 * (size_t)n + a];
+                const float half = 0.5f * (hi - lo), centre = lo + half;
+                out[4 * (size_t)ch + a] = ((c >> a) & 1u) ? centre : lo;
+                mx[3 * (size_t)ch + a] = ((c >> a) & 1u) ? hi : centre;
+            }
+            out[4 * (size_t)ch + 3] = out[4 * (size_t)n + 3] * 0.5f;
+        }
+    }
+    free(mx);
+}
 
 static void prim_tables(const orc_scene* S, uint32_t** first_prim_out, uint32_t** prim_obj_out)
 {
@@ -666,17 +694,25 @@ static void prim_tables(const orc_scene* S, uint32_t** first_prim_out, uint32_t*
     *first_prim_out = first_prim; *prim_obj_out = prim_obj;
 }
 
+/* OctreeWalk::visit of csrc/mcrt_device.h, step by step: pop, the node's tight box, the octants the ray passes from the
+ * cell's faces and mid planes (no child record is read), then the node's own list. */
 static hit_t octree_hit(const orc_scene* S, const orc_octree* T, const uint32_t* first_prim, const uint32_t* prim_obj, v3 ro, v3 rd,
                         orc_octree_stats* st, int* overflow)
 {
     enum { STACK = 128 };
     uint64_t gate_known = 0, gate_pass = 0;
-    /* slab_rcp of csrc/mcrt_device.h: the reciprocal clamped to +-FLT_MAX so that (face - origin) * inv is never NaN */
-    float inv[3] = { 1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z };
+    /* slab_rcp of csrc/mcrt_device.h: the reciprocal clamped to +-2^100 so that every product below stays finite */
+    const float RCP_MAX = 1.2676506002282294e30f;
+    float inv[3] = { 1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z }, padt[3];
     const float dd[3] = { rd.x, rd.y, rd.z };
-    for (int a = 0; a < 3; ++a) if (!(fabsf(inv[a]) <= FLT_MAX)) inv[a] = copysignf(FLT_MAX, dd[a]);
+    uint32_t flip = 0;
+    for (int a = 0; a < 3; ++a) {
+        if (!(fabsf(inv[a]) <= RCP_MAX)) inv[a] = copysignf(RCP_MAX, dd[a]);
+        padt[a] = T->pad * fabsf(inv[a]);
+        if (inv[a] < 0.0f) flip |= 1u << a;
+    }
     const float oo[3] = { ro.x, ro.y, ro.z };
-    const uint32_t flip = (rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u);
+    const float root_size[3] = { T->root_cell[3] - T->root_cell[0], T->root_cell[4] - T->root_cell[1], T->root_cell[5] - T->root_cell[2] };
     hit_t best = { -1, 0, FLT_MAX };
     uint32_t bestPrim = 0xFFFFFFFFu;
     uint32_t stack_node[STACK]; float stack_t[STACK];
@@ -688,6 +724,39 @@ static hit_t octree_hit(const orc_scene* S, const orc_octree* T, const uint32_t*
         uint32_t node = stack_node[sp];
         if (stack_t[sp] > best.t) continue;
         if (st) st->nodes++;
+        {
+            const float* b = T->box + 6 * (size_t)node;
+            float t0 = 0.0f, t1 = best.t;
+            for (int a = 0; a < 3; ++a) {
+                float x = (b[a] - oo[a]) * inv[a], y = (b[3 + a] - oo[a]) * inv[a];
+                t0 = fmaxf(t0, fminf(x, y)); t1 = fminf(t1, fmaxf(x, y));
+            }
+            if (!(t0 <= t1)) continue;
+        }
+        uint32_t cw = T->words[2 * (size_t)node];
+        uint32_t base = cw & 0x00FFFFFFu, mask = cw >> 24;
+        if (mask) {
+            const float* cell = T->cell + 4 * (size_t)node;
+            float n_in[3], n_out[3], f_in[3], f_out[3];
+            for (int a = 0; a < 3; ++a) {
+                const float size = root_size[a] * cell[3];
+                const float mid = cell[a] + 0.5f * size, cmx = cell[a] + size;
+                const int back = (flip >> a) & 1u;
+                const float tn = ((back ? cmx : cell[a]) - oo[a]) * inv[a];
+                const float tm = (mid - oo[a]) * inv[a];
+                const float tf = ((back ? cell[a] : cmx) - oo[a]) * inv[a];
+                n_in[a] = tn - padt[a]; n_out[a] = tm + padt[a];
+                f_in[a] = tm - padt[a]; f_out[a] = tf + padt[a];
+            }
+            for (int k = 7; k >= 0; --k) {
+                const float t0 = fmaxf(fmaxf((k & 1) ? f_in[0] : n_in[0], (k & 2) ? f_in[1] : n_in[1]), fmaxf((k & 4) ? f_in[2] : n_in[2], 0.0f));
+                const float t1 = fminf(fminf((k & 1) ? f_out[0] : n_out[0], (k & 2) ? f_out[1] : n_out[1]), fminf((k & 4) ? f_out[2] : n_out[2], best.t));
+                const uint32_t oct = (uint32_t)k ^ flip;
+                if (!(mask & (1u << oct)) || !(t0 <= t1)) continue;
+                const uint32_t child = base + (uint32_t)__builtin_popcount(mask & ((1u << oct) - 1u));
+                if (sp < STACK) { stack_node[sp] = child; stack_t[sp] = t0; ++sp; } else *overflow = 1;
+            }
+        }
         uint32_t ref = T->words[2 * (size_t)node + 1];
         if (ref != 0xFFFFFFFFu) {
             uint32_t e;
@@ -712,22 +781,6 @@ static hit_t octree_hit(const orc_scene* S, const orc_octree* T, const uint32_t*
                 better = h && (t < best.t || (t == best.t && bestPrim != 0xFFFFFFFFu && prim < bestPrim));
                 if (better) { best.obj = (int32_t)ob; best.elem = el; best.t = t; bestPrim = prim; }
             } while (!(e & 0x80000000u));
-        }
-        uint32_t cw = T->words[2 * (size_t)node];
-        uint32_t base = cw & 0x00FFFFFFu, mask = cw >> 24;
-        if (mask) {
-            for (int k = 7; k >= 0; --k) {
-                uint32_t oct = (uint32_t)k ^ flip;
-                if (!(mask & (1u << oct))) continue;
-                uint32_t child = base + (uint32_t)__builtin_popcount(mask & ((1u << oct) - 1u));
-                const float* b = T->box + 6 * (size_t)child;
-                float t0 = 0.0f, t1 = best.t;
-                for (int a = 0; a < 3; ++a) {
-                    float x = (b[a] - oo[a]) * inv[a], y = (b[3 + a] - oo[a]) * inv[a];
-                    t0 = fmaxf(t0, fminf(x, y)); t1 = fminf(t1, fmaxf(x, y));
-                }
-                if (t0 <= t1) { if (sp < STACK) { stack_node[sp] = child; stack_t[sp] = t0; ++sp; } else *overflow = 1; }
-            }
         }
     }
     return best;
@@ -755,7 +808,11 @@ ORC_EXPORT void orc_scene_attach_octree(orc_scene* S, const orc_octree* T, uint3
     size_t nb = sizeof(float) * 6 * (size_t)T->node_count, nw = sizeof(uint32_t) * 2 * (size_t)T->node_count, nr = sizeof(uint32_t) * (size_t)(ref_count ? ref_count : 1);
     tr->box = (float*)malloc(nb); tr->words = (uint32_t*)malloc(nw); tr->refs = (uint32_t*)malloc(nr);
     memcpy(tr->box, T->box, nb); memcpy(tr->words, T->words, nw); memcpy(tr->refs, T->refs, sizeof(uint32_t) * (size_t)ref_count);
-    tr->view.node_count = T->node_count; tr->view.box = tr->box; tr->view.words = tr->words; tr->view.refs = tr->refs;
+    tr->cell = (float*)malloc(sizeof(float) * 4 * (size_t)T->node_count);
+    tr->view = *T;
+    tr->view.box = tr->box; tr->view.words = tr->words; tr->view.refs = tr->refs; tr->view.cell = tr->cell;
+    if (T->cell) memcpy(tr->cell, T->cell, sizeof(float) * 4 * (size_t)T->node_count);
+    else orc_octree_cells(&tr->view, tr->cell);
     prim_tables(S, &tr->first_prim, &tr->prim_obj);
     orc_scene_detach_octree(S);
     S->tree = tr;
@@ -771,7 +828,7 @@ static hit_t scene_hit_octree(const orc_scene* S, v3 o, v3 d, orc_stats* st)
 }
 static void orc_tree_free(struct orc_tree* t)
 {
-    free(t->box); free(t->words); free(t->refs); free(t->first_prim); free(t->prim_obj); free(t);
+    free(t->box); free(t->words); free(t->refs); free(t->cell); free(t->first_prim); free(t->prim_obj); free(t);
 }
 
 /* ---------------------------------------------------------------- materials */

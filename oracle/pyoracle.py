@@ -58,7 +58,8 @@ class Stats(C.Structure):
 
 
 class OctreeView(C.Structure):
-    _fields_ = [("node_count", C.c_uint32), ("box", C.POINTER(C.c_float)), ("words", C.POINTER(C.c_uint32)), ("refs", C.POINTER(C.c_uint32))]
+    _fields_ = [("node_count", C.c_uint32), ("box", C.POINTER(C.c_float)), ("words", C.POINTER(C.c_uint32)), ("refs", C.POINTER(C.c_uint32)),
+                ("root_cell", C.c_float * 6), ("pad", C.c_float), ("cell", C.POINTER(C.c_float))]
 
 
 class OctreeStats(C.Structure):
@@ -186,11 +187,23 @@ class Oracle:
         )
         return obj, elem, t
 
-    def intersect_octree(self, scene, node_box, node_words, prim_refs, origins, dirs, stats=None):
-        """Replay the product's flat octree on the CPU (leaf tests are the oracle's)."""
-        o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)
+    def _tree(self, info, node_box, node_words, prim_refs):
+        """OctreeView over the downloaded arrays; the node cells are derived from the root cell of `info` (mcrt_octree_info)."""
         box, words, refs = _f32(node_box), _u32(node_words), _u32(prim_refs)
-        tree = OctreeView(len(box.reshape(-1, 6)), _p(box, C.c_float), _p(words, C.c_uint32), _p(refs, C.c_uint32))
+        n = len(box.reshape(-1, 6))
+        tree = OctreeView(n, _p(box, C.c_float), _p(words, C.c_uint32), _p(refs, C.c_uint32))
+        tree.root_cell[:] = list(info.root_cell_min) + list(info.root_cell_max)
+        tree.pad = float(info.pad)
+        cells = np.zeros((n, 4), np.float32)
+        tree.cell = None
+        self.lib.orc_octree_cells(C.byref(tree), _p(cells, C.c_float))
+        tree.cell = _p(cells, C.c_float)
+        return tree, (box, words, refs, cells)
+
+    def intersect_octree(self, scene, info, node_box, node_words, prim_refs, origins, dirs, stats=None):
+        """Replay the product's flat octree walk on the CPU (leaf tests are the oracle's)."""
+        o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)
+        tree, keep = self._tree(info, node_box, node_words, prim_refs)
         n = len(o)
         obj = np.zeros(n, np.int32); elem = np.zeros(n, np.uint32); t = np.zeros(n, np.float32)
         self.lib.orc_intersect_octree.restype = C.c_int
@@ -201,11 +214,10 @@ class Oracle:
         assert overflow == 0, "traversal stack overflow in the replay"
         return obj, elem, t
 
-    def attach_octree(self, scene, node_box, node_words, prim_refs):
+    def attach_octree(self, scene, info, node_box, node_words, prim_refs):
         """Every later nearest-hit query of `scene` (intersect, trace, render) walks this flat octree (copied)."""
-        box, words, refs = _f32(node_box), _u32(node_words), _u32(prim_refs)
-        tree = OctreeView(len(box.reshape(-1, 6)), _p(box, C.c_float), _p(words, C.c_uint32), _p(refs, C.c_uint32))
-        self.lib.orc_scene_attach_octree(C.c_void_p(scene.h), C.byref(tree), C.c_uint32(len(refs)))
+        tree, keep = self._tree(info, node_box, node_words, prim_refs)
+        self.lib.orc_scene_attach_octree(C.c_void_p(scene.h), C.byref(tree), C.c_uint32(len(keep[2])))
 
     def detach_octree(self, scene):
         self.lib.orc_scene_detach_octree(C.c_void_p(scene.h))

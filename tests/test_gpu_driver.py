@@ -269,8 +269,8 @@ def test_config4_image_size_on_the_million_triangle_scene(backend, pkg, oracle, 
     assert np.array_equal(a, backend.read_accumulator())
     assert np.isfinite(a).all() and a.mean() > 0
     sc = oracle.scene(flat)
-    _, box, words, refs = pkg.build_scene_image(flat)
-    oracle.attach_octree(sc, box, words, refs)                           # the oracle walks the same flat octree (brute force: 10^6 tests per ray)
+    info, box, words, refs = pkg.build_scene_image(flat)
+    oracle.attach_octree(sc, info, box, words, refs)                          # the oracle walks the same flat octree (brute force: 10^6 tests per ray)
     rng = np.random.default_rng(13)
     px = np.concatenate([rng.integers(0, 2048 * 2048, 6), [1024 * 2048 + 1024, 1023 * 2048 + 1024]]).astype(np.uint32)   # + the pixels around the image centre
     _check_pixels(backend, oracle, sc, cam, spp, a, px)

@@ -209,7 +209,7 @@ def test_octree_equals_brute_force_on_cpu(pkg, oracle, po, scene_of, golden, nam
     for accel in (None, pkg.AccelParams(1, 12, 0.0), pkg.AccelParams(16, 2, 0.0), pkg.AccelParams(2, 6, 1e-6)):
         info, box, words, refs = pkg.build_scene_image(flat, accel)
         st = po.OctreeStats()
-        obj, elem, t = oracle.intersect_octree(sc, box, words, refs, g["origins"], g["dirs"], stats=st)
+        obj, elem, t = oracle.intersect_octree(sc, info, box, words, refs, g["origins"], g["dirs"], stats=st)
         assert np.array_equal(obj, g["obj"]) and np.array_equal(elem, g["elem"]) and np.array_equal(t, g["t"])
         assert st.nodes >= st.rays
 
