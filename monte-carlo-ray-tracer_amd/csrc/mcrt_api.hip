@@ -185,66 +185,52 @@ struct ExplicitStart {
 // cannot move a draw).  What waits for the shadow query is one comparison and one multiply-add.
 // kMulti: scenes with more than one light test the further lights one query at a time from a saved copy of the
 // generator (the state that path needs is compiled out of the one-light kernels).
-template <class PS, class PB, int kAccel, bool kCount, bool kMulti, class Work>
-__device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, const CameraDev& cam, uint64_t seed, uint32_t max_depth,
-                                           const PendStack& pend, bool keep_nonfinite, Counters& cn, RenderCounters& rc, Work& work,
-                                           const LanePolicy policy, uint32_t* walk_lds)
-{
-    D3 sum = dmk(0.0, 0.0, 0.0);
-    uint32_t dropped = 0;
-    uint32_t pixel = 0, s_begin = 0, s_count = 0, px = 0, py = 0;
-    ExplicitStart exs;
-    const ExplicitStart* ex = nullptr;
-    const D3 background = ldd3(sm, v.off_bg);
-
-    uint32_t state = ST_FETCH;
-    uint32_t k = 0;
-    Rng g; g.s0 = 0; g.s1 = 0;
-    V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);       // ray of the current query
-    D3 imp = dmk(1, 1, 1), L = dmk(0, 0, 0);
-    uint32_t depth = 0, npend = 0;
+// The per-lane state of the estimator between two nearest-hit queries, and the two halves of one loop iteration around the
+// query: pre() - take the next work item / start the next camera sample, so that the lane has a ray - and post() - shade the
+// hit (source/scene.cpp:94-234).  The render kernels run pre / query / post in one loop per lane (trace_lane); the wavefront
+// pipeline (k_wf_shade / k_wf_trace, big scenes) keeps the same state in HBM between kernels and runs the same two functions,
+// so both produce the same numbers by construction.
+template <bool kMulti> struct LaneState {
+    D3 sum;
+    uint32_t dropped;
+    uint32_t pixel, s_begin, s_count;
+    uint32_t state;
+    uint32_t k;
+    Rng g;
+    V3 ro, rd;                  // ray of the current query
+    D3 imp, L;
+    uint32_t depth, npend;
     // diffuse-hit context kept across the shadow queries
-    V3 hp = mk(0, 0, 0), bd = mk(0, 0, 0);        // hit point (origin of the shadow rays and of the bounce), bounce direction
-    D3 impc = dmk(0, 0, 0);                        // importance * surface colour, scene.cpp:148
-    D3 direct = dmk(0, 0, 0);
-    double p_survive = 1.0, g_bounce = 0.0;       // roulette threshold; 2 * cosTheta * BRDF(bounce), scene.cpp:164
-    double w_light = 0.0;                          // BRDF(light) * surfaceDot * lightDot of the light under test, scene.cpp:136-139
-    bool survive = false;
-    uint32_t light_i = 0;
+    V3 hp, bd;                  // hit point (origin of the shadow rays and of the bounce), bounce direction
+    D3 impc;                    // importance * surface colour, scene.cpp:148
+    D3 direct;
+    double p_survive, g_bounce; // roulette threshold; 2 * cosTheta * BRDF(bounce), scene.cpp:164
+    double w_light;             // BRDF(light) * surfaceDot * lightDot of the light under test, scene.cpp:136-139
+    bool survive;
+    uint32_t light_i;
     // kMulti only: what sampling and shading a further light needs
-    V3 hn = mk(0, 0, 0), hd = mk(0, 0, 0);
-    uint32_t horec = 0;
-    Rng g_l; g_l.s0 = 0; g_l.s1 = 0;
+    V3 hn, hd;
+    uint32_t horec;
+    Rng g_l;
 
-    // Fetch policy: idle lanes wait until fetch_min of them can fetch together (or nobody is left working); they then receive
-    // consecutive items - neighbouring pixels of one tile - which keeps the wavefront's rays coherent (the wave-uniform scan
-    // culls whole meshes per wavefront).  fetch_min == 64 is a round: everybody waits for the slowest lane.
-    const uint32_t kMinTrace = policy.min_trace, kFetchMin = policy.fetch_min;
-    // Octree path: the nearest-hit query is resumable (OctreeWalk): lanes whose ray is finished are shaded
-    // and given their next ray while the others stay in mid-traversal.
-    constexpr bool kWalk = (kAccel == MCRT_ACCEL_OCTREE);
-    OctreeWalk<PS, PB, kCount> walk;
-    // walks through an HBM-resident image keep the top of their stack in LDS (walk_lds), see LdsStack
-    typename WalkStackFor<PB>::type walk_stack;
-    WalkStackFor<PB>::bind(walk_stack, walk_lds);
-    bool walking = false;
-    if (kWalk) walk.idle();
+    __device__ __forceinline__ void init()
+    {
+        sum = dmk(0.0, 0.0, 0.0); dropped = 0; pixel = s_begin = s_count = 0; state = ST_FETCH; k = 0;
+        g.s0 = 0; g.s1 = 0; ro = mk(0, 0, 0); rd = mk(0, 0, 1); imp = dmk(1, 1, 1); L = dmk(0, 0, 0); depth = 0; npend = 0;
+        hp = mk(0, 0, 0); bd = mk(0, 0, 0); impc = dmk(0, 0, 0); direct = dmk(0, 0, 0); p_survive = 1.0; g_bounce = 0.0; w_light = 0.0;
+        survive = false; light_i = 0; hn = mk(0, 0, 0); hd = mk(0, 0, 0); horec = 0; g_l.s0 = 0; g_l.s1 = 0;
+    }
 
-    // The loop is wave-uniform: a lane that has nothing left stays in it as a helper (the cooperative queries need all 64 lanes).
-    for (;;) {
-        const uint64_t busy = __ballot(state != ST_DONE);
-        if (busy == 0ull) break;
-        bool fetch_ok = true;
-        if (kFetchMin > 1u) {
-            const uint64_t want = __ballot(state == ST_FETCH);
-            fetch_ok = (uint32_t)__popcll(want) >= kFetchMin || want == busy;
-        }
+    // Before the query: a lane without an item takes the next one (when `fetch_ok`), a lane between samples starts the next sample.
+    // (no early return on the fetch path: in the render kernels every lane has to arrive at the cooperative query that follows)
+    template <class Work>
+    __device__ __forceinline__ void pre(bool fetch_ok, Work& work, const CameraDev& cam, uint64_t seed, uint32_t max_depth, ExplicitStart& exs,
+                                        const ExplicitStart*& ex, RenderCounters& rc, bool count)
+    {
         if (state == ST_FETCH && fetch_ok) {
-            // (no `continue` on this path: every lane has to arrive at the cooperative query below)
             if (!work.next(pixel, s_begin, s_count)) state = ST_DONE;
             else {
                 ex = work.explicit_start(exs) ? &exs : nullptr;
-                px = pixel % cam.width; py = pixel / cam.width;
                 k = 0; sum = dmk(0.0, 0.0, 0.0); dropped = 0;
                 state = ST_NEW;
             }
@@ -263,43 +249,30 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
                 g.s0 = a; g.s1 = b;
                 float sx = rng_float(g);
                 float sy = rng_float(g);
+                const uint32_t px = pixel % cam.width, py = pixel / cam.width;
                 camera_ray(cam, (float)px + sx, (float)py + sy, ro, rd);
             }
             L = dmk(0.0, 0.0, 0.0);
             depth = max_depth;
             npend = 0;
             state = ST_TRACE;
-            if (kCount) rc.samples++;
+            if (count) rc.samples++;
         }
+    }
 
-        Hit hit;
-        {
-            // Batching of the shading: a lane with a shadow ray is always served (what follows its query is one comparison and a
-            // multiply-add); lanes with a camera / bounce ray are served when at least kMinTrace of them are waiting (or nobody has
-            // a shadow ray), otherwise they sit this query out - after it every shadow lane has turned into a trace lane, so the
-            // wait is one iteration.  The wavefront executes the whole shading of a hit whenever ANY lane needs it; this way it pays
-            // for that about every other iteration, with most of its lanes in it, instead of every iteration for a minority.
-            // Break-even by the instruction counts (cast ~2050, shading ~1200 per wavefront): wait when fewer than ~3/8 of the lanes are ready;
-            // measured optimum of the threshold over configs 1, 2, 3 and 5: 36 (sweep 0 / 12 / 24 / 36 / 64, profiles/r02_sweep_min_trace.txt).
-            bool live = state != ST_FETCH && state != ST_DONE;          // a lane waiting for an item, or finished, has no ray
-            if (kMinTrace > 0u && live) {
-                const bool is_s = state == ST_SHADOW;
-                const uint32_t n_s = (uint32_t)__popcll(__ballot(is_s)), n_t = (uint32_t)__popcll(__ballot(!is_s));
-                live = is_s || n_t >= kMinTrace || n_s == 0u;
-            }
-            if constexpr (kWalk) {
-                // a lane without a ray has an empty stack: it sits in the walk loop as a finished lane
-                if (live && !walking) { walk.begin(big, v, walk_stack, cn); walking = true; }
-                walk.run(sm, big, v, walk_stack, ro, rd, cn, policy.refill & 0xFFu, policy.refill >> 8);
-                if (!live || !walk.done()) continue;          // no ray, or still in mid-traversal: nothing to shade yet
-                walking = false;
-                hit = walk.best;
-            } else {
-                hit = cast<kAccel, PS, PB, kCount>(sm, big, v, ro, rd, cn, live);
-                if (!live) continue;
-            }
-        }
-
+    // After the query.  A wavefront executes every piece of code that ANY of its lanes needs in an iteration, and with 64 lanes in 64
+    // different path states that is nearly all of it, every iteration: the cost of the loop is its static size.  So the
+    // shading of a diffuse hit is laid out to exist once: everything that follows from the hit alone - the light sample,
+    // the roulette draw, the hemisphere bounce, the BRDF towards the light AND towards the bounce (brdf2: one copy of the
+    // Oren-Nayar trigonometry serves both) - is computed when the hit is shaded, in the reference's draw order
+    // (scene.cpp:127-164: light points, roulette, hemisphere; the shadow ray consumes no random numbers, so its outcome
+    // cannot move a draw).  What waits for the shadow query is one comparison and one multiply-add.
+    // kMulti: scenes with more than one light test the further lights one query at a time from a saved copy of the
+    // generator (the state that path needs is compiled out of the one-light kernels).
+    template <class PS, class PB, class Work>
+    __device__ __forceinline__ void post(const Hit& hit, PS sm, PB big, const SceneView& v, const D3& background, const PendStack& pend, bool keep_nonfinite,
+                                         Work& work, const ExplicitStart* ex, RenderCounters& rc, bool count)
+    {
         bool branch_done = false;      // this TraceRay chain returned; continue with a parked branch or finish the sample
         bool lights_done = false;      // every light of the current diffuse hit is accounted for
         bool eval_light = false, eval_bounce = false;   // BRDF values wanted this iteration: towards `ldir`, towards `bd`
@@ -307,7 +280,7 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
         uint32_t eorec = 0;
         float cosTheta = 0.0f;
         if (state == ST_TRACE) {
-            if (kCount) rc.trace_calls++;
+            if (count) rc.trace_calls++;
             if (hit.obj == MISS) {
                 L = L + imp * background;                                   // scene.cpp:97-100
                 branch_done = true;
@@ -378,7 +351,7 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
                                 const D3 pimp = imp * (double)R;
                                 pend.push(npend, refl_o, refl_d, pimp, depth - 1);
                                 npend += 1;
-                                if (kCount) rc.splits++;
+                                if (count) rc.splits++;
                                 imp = imp * (double)(1.0 - R);
                                 ro = p - errorMargin; rd = tdir; depth -= 1;
                             } else {
@@ -451,6 +424,77 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
                 else { work.done(pixel, sum, dropped); state = ST_FETCH; }
             }
         }
+    }
+};
+
+// One lane of a tracing kernel.  `work` hands out items - samples [s_begin, s_begin + s_count) of a
+// pixel - one at a time (Work::next) and takes back the sum of the item's finite samples in sample
+// order plus the number dropped (Work::done; keep_nonfinite: the raw value, used by the parity path
+// with s_count == 1).  Every loop iteration is exactly one nearest-hit query: LaneState::pre, the query, LaneState::post.
+template <class PS, class PB, int kAccel, bool kCount, bool kMulti, class Work>
+__device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, const CameraDev& cam, uint64_t seed, uint32_t max_depth,
+                                           const PendStack& pend, bool keep_nonfinite, Counters& cn, RenderCounters& rc, Work& work,
+                                           const LanePolicy policy, uint32_t* walk_lds)
+{
+    LaneState<kMulti> ln;
+    ln.init();
+    ExplicitStart exs;
+    const ExplicitStart* ex = nullptr;
+    const D3 background = ldd3(sm, v.off_bg);
+
+    // Fetch policy: idle lanes wait until fetch_min of them can fetch together (or nobody is left working); they then receive
+    // consecutive items - neighbouring pixels of one tile - which keeps the wavefront's rays coherent (the wave-uniform scan
+    // culls whole meshes per wavefront).  fetch_min == 64 is a round: everybody waits for the slowest lane.
+    const uint32_t kMinTrace = policy.min_trace, kFetchMin = policy.fetch_min;
+    // Octree path: the nearest-hit query is resumable (OctreeWalk): lanes whose ray is finished are shaded
+    // and given their next ray while the others stay in mid-traversal.
+    constexpr bool kWalk = (kAccel == MCRT_ACCEL_OCTREE);
+    OctreeWalk<PS, PB, kCount> walk;
+    // walks through an HBM-resident image keep the top of their stack in LDS (walk_lds), see LdsStack
+    typename WalkStackFor<PB>::type walk_stack;
+    WalkStackFor<PB>::bind(walk_stack, walk_lds);
+    bool walking = false;
+    if (kWalk) walk.idle();
+
+    // The loop is wave-uniform: a lane that has nothing left stays in it as a helper (the cooperative queries need all 64 lanes).
+    for (;;) {
+        const uint64_t busy = __ballot(ln.state != ST_DONE);
+        if (busy == 0ull) break;
+        bool fetch_ok = true;
+        if (kFetchMin > 1u) {
+            const uint64_t want = __ballot(ln.state == ST_FETCH);
+            fetch_ok = (uint32_t)__popcll(want) >= kFetchMin || want == busy;
+        }
+        ln.pre(fetch_ok, work, cam, seed, max_depth, exs, ex, rc, kCount);
+
+        Hit hit;
+        {
+            // Batching of the shading: a lane with a shadow ray is always served (what follows its query is one comparison and a
+            // multiply-add); lanes with a camera / bounce ray are served when at least kMinTrace of them are waiting (or nobody has
+            // a shadow ray), otherwise they sit this query out - after it every shadow lane has turned into a trace lane, so the
+            // wait is one iteration.  The wavefront executes the whole shading of a hit whenever ANY lane needs it; this way it pays
+            // for that about every other iteration, with most of its lanes in it, instead of every iteration for a minority.
+            // Break-even by the instruction counts (cast ~2050, shading ~1200 per wavefront): wait when fewer than ~3/8 of the lanes are ready;
+            // measured optimum of the threshold over configs 1, 2, 3 and 5: 36 (sweep 0 / 12 / 24 / 36 / 64, profiles/r02_sweep_min_trace.txt).
+            bool live = ln.state != ST_FETCH && ln.state != ST_DONE;          // a lane waiting for an item, or finished, has no ray
+            if (kMinTrace > 0u && live) {
+                const bool is_s = ln.state == ST_SHADOW;
+                const uint32_t n_s = (uint32_t)__popcll(__ballot(is_s)), n_t = (uint32_t)__popcll(__ballot(!is_s));
+                live = is_s || n_t >= kMinTrace || n_s == 0u;
+            }
+            if constexpr (kWalk) {
+                // a lane without a ray has an empty stack: it sits in the walk loop as a finished lane
+                if (live && !walking) { walk.begin(big, v, walk_stack, cn); walking = true; }
+                walk.run(sm, big, v, walk_stack, ln.ro, ln.rd, cn, policy.refill & 0xFFu, policy.refill >> 8);
+                if (!live || !walk.done()) continue;          // no ray, or still in mid-traversal: nothing to shade yet
+                walking = false;
+                hit = walk.best;
+            } else {
+                hit = cast<kAccel, PS, PB, kCount>(sm, big, v, ln.ro, ln.rd, cn, live);
+                if (!live) continue;
+            }
+        }
+        ln.post(hit, sm, big, v, background, pend, keep_nonfinite, work, ex, rc, kCount);
     }
 }
 
