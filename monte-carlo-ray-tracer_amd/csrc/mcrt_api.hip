@@ -609,6 +609,227 @@ __global__ __launch_bounds__(kBlock, 4) void k_render(const RenderArgs a)
     if (kCount) flush_counters(a.counters, cn, rc);
 }
 
+// ------------------------------------------------------------------ wavefront pipeline (scenes walked from HBM)
+// For a scene whose octree lives in HBM a lane of k_render spends its time in OctreeWalk, carrying the whole estimator
+// state (LaneState, ~64 registers) along, at 4 wavefronts per SIMD, with lanes idle whenever their ray ends before their
+// neighbours' (measured: 15-17 of 64 lanes active per instruction).  The wavefront pipeline cuts the loop at the query:
+//   k_wf_shade   one thread per path SLOT whose query has been answered: LaneState::post, LaneState::pre (the same two
+//                functions k_render runs), state back to HBM, the slot appended to the queue of slots with a new ray;
+//   k_wf_trace   persistent wavefronts that only walk: a lane takes the next queued slot the moment its ray is finished
+//                (one aggregated atomic per wavefront and fetch), so every lane walks all the time, and the kernel needs
+//                half the registers: more wavefronts per SIMD to hide the dependent loads of a visit.
+// A slot is a virtual lane of k_render: it works off its items (sample slices of pixels) one sample after the other and
+// hands back sums in sample order, so the accumulators are bit-identical to k_render's.  State lives in HBM as 16-byte
+// chunks, chunk-major (chunk c of slot s at [c * slots + s]): consecutive slots, coalesced accesses.
+constexpr uint32_t kWfChunks = 16, kWfChunksMulti = 19;
+constexpr uint32_t WF_NONE = 0xFFFFFFFFu;
+constexpr uint32_t kWfBatch = 64;           // queue entries a wavefront of k_wf_trace takes per atomic
+enum : uint32_t { WF_CNT_Q0 = 0, WF_CNT_Q1 = 1, WF_CNT_CURSOR = 2, WF_CNT_WORDS = 8 };
+
+struct WfArgs {
+    RenderArgs r;
+    U4* state;               // [chunks][slots]
+    U4* hits;                // [slots]: prim, obj, elem, t of the slot's last query
+    const uint32_t* q_in;    // slots whose query was answered (shade) / slots with a ray (trace)
+    uint32_t* q_out;         // shade: slots that have a new ray
+    uint32_t* cnt;           // WF_CNT_*
+    uint32_t in_idx, out_idx;   // which of cnt[Q0], cnt[Q1] counts q_in / q_out
+    uint32_t slots;
+    uint32_t first;          // shade: no answered queries yet - every slot starts from scratch
+};
+
+__device__ __forceinline__ U4 u4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { U4 r; r.x = a; r.y = b; r.z = c; r.w = d; return r; }
+__device__ __forceinline__ uint32_t dlo(double v) { return (uint32_t)(uint64_t)__double_as_longlong(v); }
+__device__ __forceinline__ uint32_t dhi(double v) { return (uint32_t)((uint64_t)__double_as_longlong(v) >> 32); }
+__device__ __forceinline__ double dmake(uint32_t lo, uint32_t hi) { return __longlong_as_double((long long)((uint64_t)lo | ((uint64_t)hi << 32))); }
+__device__ __forceinline__ U4 dd4(double a, double b) { return u4(dlo(a), dhi(a), dlo(b), dhi(b)); }
+
+template <bool kMulti>
+__device__ __forceinline__ void wf_store(const LaneState<kMulti>& s, uint32_t slice, U4* st, uint32_t slots, uint32_t slot)
+{
+    U4* p = st + slot;
+    const size_t n = slots;
+    p[0 * n] = u4(__float_as_uint(s.ro.x), __float_as_uint(s.ro.y), __float_as_uint(s.ro.z), s.state);
+    p[1 * n] = u4(__float_as_uint(s.rd.x), __float_as_uint(s.rd.y), __float_as_uint(s.rd.z), s.depth);
+    p[2 * n] = u4((uint32_t)s.g.s0, (uint32_t)(s.g.s0 >> 32), (uint32_t)s.g.s1, (uint32_t)(s.g.s1 >> 32));
+    p[3 * n] = dd4(s.imp.x, s.imp.y);
+    p[4 * n] = dd4(s.imp.z, s.L.x);
+    p[5 * n] = dd4(s.L.y, s.L.z);
+    p[6 * n] = dd4(s.sum.x, s.sum.y);
+    p[7 * n] = u4(dlo(s.sum.z), dhi(s.sum.z), s.pixel, s.s_begin);
+    p[8 * n] = u4(s.s_count, s.k, s.dropped, s.npend);
+    p[9 * n] = u4(__float_as_uint(s.hp.x), __float_as_uint(s.hp.y), __float_as_uint(s.hp.z), s.light_i | (s.survive ? 0x80000000u : 0u));
+    p[10 * n] = u4(__float_as_uint(s.bd.x), __float_as_uint(s.bd.y), __float_as_uint(s.bd.z), slice);
+    p[11 * n] = dd4(s.impc.x, s.impc.y);
+    p[12 * n] = dd4(s.impc.z, s.direct.x);
+    p[13 * n] = dd4(s.direct.y, s.direct.z);
+    p[14 * n] = dd4(s.p_survive, s.g_bounce);
+    p[15 * n] = u4(dlo(s.w_light), dhi(s.w_light), s.horec, 0u);
+    if constexpr (kMulti) {
+        p[16 * n] = u4(__float_as_uint(s.hn.x), __float_as_uint(s.hn.y), __float_as_uint(s.hn.z), 0u);
+        p[17 * n] = u4(__float_as_uint(s.hd.x), __float_as_uint(s.hd.y), __float_as_uint(s.hd.z), 0u);
+        p[18 * n] = u4((uint32_t)s.g_l.s0, (uint32_t)(s.g_l.s0 >> 32), (uint32_t)s.g_l.s1, (uint32_t)(s.g_l.s1 >> 32));
+    }
+}
+
+template <bool kMulti>
+__device__ __forceinline__ void wf_load(LaneState<kMulti>& s, uint32_t& slice, const U4* st, uint32_t slots, uint32_t slot)
+{
+    const U4* p = st + slot;
+    const size_t n = slots;
+    U4 c[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = p[(size_t)i * n];
+    s.ro = mk(__uint_as_float(c[0].x), __uint_as_float(c[0].y), __uint_as_float(c[0].z)); s.state = c[0].w;
+    s.rd = mk(__uint_as_float(c[1].x), __uint_as_float(c[1].y), __uint_as_float(c[1].z)); s.depth = c[1].w;
+    s.g.s0 = (uint64_t)c[2].x | ((uint64_t)c[2].y << 32); s.g.s1 = (uint64_t)c[2].z | ((uint64_t)c[2].w << 32);
+    s.imp = dmk(dmake(c[3].x, c[3].y), dmake(c[3].z, c[3].w), dmake(c[4].x, c[4].y));
+    s.L = dmk(dmake(c[4].z, c[4].w), dmake(c[5].x, c[5].y), dmake(c[5].z, c[5].w));
+    s.sum = dmk(dmake(c[6].x, c[6].y), dmake(c[6].z, c[6].w), dmake(c[7].x, c[7].y));
+    s.pixel = c[7].z; s.s_begin = c[7].w;
+    s.s_count = c[8].x; s.k = c[8].y; s.dropped = c[8].z; s.npend = c[8].w;
+    s.hp = mk(__uint_as_float(c[9].x), __uint_as_float(c[9].y), __uint_as_float(c[9].z));
+    s.light_i = c[9].w & 0x7FFFFFFFu; s.survive = (c[9].w >> 31) != 0u;
+    s.bd = mk(__uint_as_float(c[10].x), __uint_as_float(c[10].y), __uint_as_float(c[10].z)); slice = c[10].w;
+    s.impc = dmk(dmake(c[11].x, c[11].y), dmake(c[11].z, c[11].w), dmake(c[12].x, c[12].y));
+    s.direct = dmk(dmake(c[12].z, c[12].w), dmake(c[13].x, c[13].y), dmake(c[13].z, c[13].w));
+    s.p_survive = dmake(c[14].x, c[14].y); s.g_bounce = dmake(c[14].z, c[14].w);
+    s.w_light = dmake(c[15].x, c[15].y); s.horec = c[15].z;
+    if constexpr (kMulti) {
+        const U4 a = p[16 * n], b = p[17 * n], e = p[18 * n];
+        s.hn = mk(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+        s.hd = mk(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+        s.g_l.s0 = (uint64_t)e.x | ((uint64_t)e.y << 32); s.g_l.s1 = (uint64_t)e.z | ((uint64_t)e.w << 32);
+    } else {
+        s.hn = mk(0, 0, 0); s.hd = mk(0, 0, 0); s.g_l.s0 = 0; s.g_l.s1 = 0;
+    }
+}
+
+// One step of every slot whose query has been answered: shade the hit, get the next ray ready (next sample / next item included).
+template <bool kCount, bool kMulti>
+__global__ __launch_bounds__(kBlock, 4) void k_wf_shade(const WfArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    typedef SceneMem<false, MCRT_ACCEL_OCTREE> Mem;
+    typename Mem::PS sm;
+    typename Mem::PB big;
+    Mem::open(a.r.view, smem, sm, big);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.cnt[WF_CNT_CURSOR] = 0;     // the trace kernel that follows starts at the head of q_out
+    const D3 background = ldd3(sm, a.r.view.off_bg);
+    Counters cn = { 0, 0, 0, 0, 0 };
+    RenderCounters rc = { 0, 0, 0 };
+    RenderWork work = { a.r, 0u, 0u };
+    PendStack pend;
+    pend.base = a.r.pend;
+    pend.entries = a.r.max_depth ? a.r.max_depth : 1u;
+    ExplicitStart exs;
+    const ExplicitStart* ex = nullptr;
+
+    const uint32_t n = a.first ? a.slots : a.cnt[a.in_idx];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    // whole wavefronts go round together (the ballots of the queue append need them)
+    for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < n; base += stride) {
+        const uint32_t i = base + lane;
+        const bool have = i < n;
+        uint32_t slot = WF_NONE;
+        LaneState<kMulti> ln;
+        bool active = false;
+        if (have) {
+            slot = a.first ? i : a.q_in[i];
+            pend.lane = slot;
+            if (a.first) { ln.init(); work.slice = 0; }
+            else {
+                wf_load(ln, work.slice, a.state, a.slots, slot);
+                const U4 h = a.hits[slot];
+                Hit hit; hit.prim = h.x; hit.obj = h.y; hit.elem = h.z; hit.t = __uint_as_float(h.w);
+                ln.post(hit, sm, big, a.r.view, background, pend, false, work, ex, rc, kCount);
+            }
+            ln.pre(true, work, a.r.cam, a.r.seed, a.r.max_depth, exs, ex, rc, kCount);
+            active = ln.state != ST_DONE;
+            if (active) wf_store(ln, work.slice, a.state, a.slots, slot);
+        }
+        // append the slots that have a ray to q_out: one atomic per wavefront
+        const uint64_t m = __ballot(active);
+        if (m) {
+            const uint32_t leader = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+            uint32_t at = 0;
+            if (lane == leader) at = atomicAdd(a.cnt + a.out_idx, (uint32_t)__popcll(m));
+            at = (uint32_t)__shfl((int)at, (int)leader);
+            if (active) a.q_out[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = slot;
+        }
+    }
+    if (work.dropped_total) atomicAdd(a.r.dropped, (unsigned long long)work.dropped_total);
+    if (kCount) flush_counters(a.r.counters, cn, rc);
+}
+
+// Persistent wavefronts that walk the octree for the queued slots; a lane takes the next slot the moment its ray is finished.
+template <bool kCount, int kStackEntries, int kBlocksPerCu>
+__global__ __launch_bounds__(kBlock, kBlocksPerCu) void k_wf_trace(const WfArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const SceneView& v = a.r.view;
+    stage_scene<false>(v, smem);
+    const LdsPtr sm = (LdsPtr)smem;
+    const GlbPtr big = v.big_img;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.cnt[a.out_idx] = 0;        // the shade kernel that follows appends to an empty queue
+    LdsStackT<kStackEntries> st;
+    st.col = (__attribute__((address_space(3))) uint32_t*)(smem + ((v.small_words + 3u) & ~3u)) + threadIdx.x;
+    Counters cn = { 0, 0, 0, 0, 0 };
+    RenderCounters rc = { 0, 0, 0 };
+    OctreeWalk<LdsPtr, GlbPtr, kCount> walk;
+    walk.idle();
+    const uint32_t n = a.cnt[a.in_idx];
+    const uint32_t lane = threadIdx.x & 63u;
+    const GlbPtr nodes = big + v.off_node, leaves = big + v.off_leaf;
+    uint32_t slot = WF_NONE;
+    bool exhausted = false;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), inv = mk(0, 0, 0), padt = mk(0, 0, 0);
+    uint32_t flip = 0;
+    // The wavefront owns a batch of queue entries [w_pos, w_end) (wave-uniform): lanes that need a ray take from it, the
+    // batch is refilled with ONE atomic per kWfBatch entries - a per-fetch atomic on the one cursor serialised in L2
+    // (measured: 2 M rays took 12 ms of which the atomics were most).
+    uint32_t w_pos = 0, w_end = 0;
+    for (;;) {
+        const bool idle_lane = walk.sp == 0;
+        if (idle_lane && slot != WF_NONE) {
+            a.hits[slot] = u4(walk.best.prim, walk.best.obj, walk.best.elem, __float_as_uint(walk.best.t));
+            slot = WF_NONE;
+        }
+        uint64_t need = __ballot(idle_lane && !exhausted);
+        while (need) {
+            if (w_pos >= w_end) {
+                uint32_t at = 0;
+                if (lane == 0) at = atomicAdd(a.cnt + WF_CNT_CURSOR, kWfBatch);
+                at = (uint32_t)__shfl((int)at, 0);
+                w_pos = at < n ? at : n;
+                w_end = (at + kWfBatch) < n ? (at + kWfBatch) : n;
+                if (w_pos >= w_end) { exhausted = true; break; }       // the queue is empty: wave-uniform
+            }
+            const uint32_t avail = w_end - w_pos;
+            const bool mine = (need >> lane) & 1ull;
+            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            const bool take = mine && rank < avail;
+            if (take) {
+                slot = a.q_in[w_pos + rank];
+                const U4 c0 = a.state[slot], c1 = a.state[(size_t)a.slots + slot];
+                o = mk(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z));
+                d = mk(__uint_as_float(c1.x), __uint_as_float(c1.y), __uint_as_float(c1.z));
+                inv = mk(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
+                padt = mk(v.walk_pad * fabsf(inv.x), v.walk_pad * fabsf(inv.y), v.walk_pad * fabsf(inv.z));
+                flip = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+                walk.begin(big, v, st, cn);
+            }
+            const uint32_t taken = (uint32_t)__popcll(need) < avail ? (uint32_t)__popcll(need) : avail;
+            w_pos += taken;
+            need = __ballot(mine && !take);
+        }
+        if (__ballot(walk.sp > 0) == 0ull) break;     // nobody walks: every lane has stored its hit and found the queue empty
+        if (walk.sp > 0) walk.visit(sm, nodes, leaves, v, st, o, d, inv, padt, flip, 4u, cn);
+    }
+    if (kCount) flush_counters(a.r.counters, cn, rc);
+}
+
 // accumulator += ((slice 0 + slice 1) + slice 2) + ... per pixel and channel: the order the test oracle uses
 __global__ __launch_bounds__(kBlock) void k_combine(double* __restrict__ accum, const double* __restrict__ partial, uint64_t values, uint32_t slices)
 {
@@ -852,6 +1073,20 @@ struct mcrt_ctx {
     int chunk_override = 0;                     // MCRT_LEAF_CHUNK (tuning knob): LanePolicy::refill, leaf records per visit
     uint32_t wave_slices = 64;                  // MCRT_WAVE_SLICES (tuning knob): slices of a pixel that share a wavefront, at most
 
+    // wavefront pipeline (k_wf_shade / k_wf_trace): path-slot state, hits, the two slot queues, counters
+    int wavefront = -1;                         // MCRT_WAVEFRONT (tuning knob): 1 / 0 forces it on / off for HBM-resident octree scenes, -1: automatic
+    uint32_t wf_slots_override = 0;             // MCRT_WF_SLOTS (tuning knob)
+    int wf_trace_variant = 0;                   // MCRT_WF_TRACE (tuning knob): 0: 6 blocks per CU, 1: 8 blocks per CU, 2: 4 blocks per CU
+    U4* d_wf_state = nullptr;
+    U4* d_wf_hits = nullptr;
+    uint32_t* d_wf_queue = nullptr;             // 2 x slots
+    uint32_t* d_wf_cnt = nullptr;
+    uint32_t* h_wf_cnt = nullptr;               // pinned: the queue length read back every few iterations
+    uint32_t wf_slots = 0, wf_chunks = 0;
+    uint32_t* d_wf_pend = nullptr;
+    size_t wf_pend_words = 0;
+    uint32_t wf_iterations = 0;                 // of the last render (introspection)
+
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     unsigned char* noalloc_scratch = nullptr;   // this device's copy of `scratch` (hipGetSymbolAddress in mcrt_create)
@@ -1000,6 +1235,120 @@ int launch_unlit(mcrt_ctx* c, double* out)
     return c->big_in_lds ? launch_unlit_t<true, MCRT_ACCEL_OCTREE>(c, out) : launch_unlit_t<false, MCRT_ACCEL_OCTREE>(c, out);
 }
 
+// ---- wavefront pipeline, host side
+// Used for octree scenes whose image is walked from HBM (the 1M-triangle configuration).  Slots: 2^21 path slots (512 MB of
+// state), fewer when the scene has refractive surfaces: every slot then owns a parked-branch stack of max_depth 64-byte
+// lines, and the stacks together are held to 8 GB.
+bool use_wavefront(const mcrt_ctx* c)
+{
+    if (c->accel != MCRT_ACCEL_OCTREE || c->big_in_lds) return false;
+    // opt-in (MCRT_WAVEFRONT=1): measured 175 ms against k_render's 103 ms on config4_1024_16 - the walk itself runs at 13 of 64
+    // lanes per instruction whether or not finished lanes are refilled at once (profiles/r02_wavefront_experiment.txt)
+    return c->wavefront == 1;
+}
+bool scene_has_refractive(const mcrt_ctx* c)
+{
+    for (uint32_t i = 0; i < c->view.nobj; ++i)
+        if (c->flat.small_img[c->view.off_obj + (size_t)i * OBJ_STRIDE + OBJ_SURFACE] == (uint32_t)MCRT_SURFACE_REFRACTIVE) return true;
+    return false;
+}
+int ensure_wavefront(mcrt_ctx* c, uint32_t max_depth)
+{
+    const bool refr = scene_has_refractive(c);
+    uint32_t slots = c->wf_slots_override ? c->wf_slots_override : (1u << 21);
+    if (refr) {
+        const uint64_t per_slot = (uint64_t)std::max(1u, max_depth) * kPendFields * 4u;
+        while (slots > 65536u && (uint64_t)slots * per_slot > (8ull << 30)) slots >>= 1;
+    }
+    slots = (slots + 63u) & ~63u;
+    const uint32_t chunks = c->view.nlights > 1 ? kWfChunksMulti : kWfChunks;
+    if (slots != c->wf_slots || chunks > c->wf_chunks) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->d_wf_state) { (void)hipFree(c->d_wf_state); c->d_wf_state = nullptr; }
+        if (c->d_wf_hits) { (void)hipFree(c->d_wf_hits); c->d_wf_hits = nullptr; }
+        if (c->d_wf_queue) { (void)hipFree(c->d_wf_queue); c->d_wf_queue = nullptr; }
+        c->wf_slots = 0;
+        HIP_TRY(c, hipMalloc(&c->d_wf_state, (size_t)slots * chunks * sizeof(U4)));
+        HIP_TRY(c, hipMalloc(&c->d_wf_hits, (size_t)slots * sizeof(U4)));
+        HIP_TRY(c, hipMalloc(&c->d_wf_queue, (size_t)slots * 2 * sizeof(uint32_t)));
+        c->wf_slots = slots; c->wf_chunks = chunks;
+    }
+    if (!c->d_wf_cnt) HIP_TRY(c, hipMalloc(&c->d_wf_cnt, WF_CNT_WORDS * sizeof(uint32_t)));
+    if (!c->h_wf_cnt) HIP_TRY(c, hipHostMalloc((void**)&c->h_wf_cnt, WF_CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    const size_t pend_words = refr ? (size_t)slots * std::max(1u, max_depth) * kPendFields : 0;
+    if (pend_words > c->wf_pend_words) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->d_wf_pend) { (void)hipFree(c->d_wf_pend); c->d_wf_pend = nullptr; c->wf_pend_words = 0; }
+        HIP_TRY(c, hipMalloc(&c->d_wf_pend, pend_words * sizeof(uint32_t)));
+        c->wf_pend_words = pend_words;
+    }
+    return MCRT_OK;
+}
+
+// `bound`: an upper bound of the queue length the kernel will find (the queue never grows: a slot that has run out of work does not
+// come back), so that the drained tail of a render does not launch - and stage the scene into - thousands of idle workgroups
+uint32_t wf_grid(uint32_t full, uint32_t bound) { return std::max(1u, std::min(full, (bound + kBlock - 1u) / kBlock)); }
+
+template <bool kCount> int launch_wf_shade(mcrt_ctx* c, const WfArgs& a, uint32_t bound)
+{
+    const size_t lds = c->lds_bytes;
+    const uint32_t grid = wf_grid(grid_for(c), bound);
+    if (c->view.nlights > 1) hipLaunchKernelGGL((k_wf_shade<kCount, true>), dim3(grid), dim3(kBlock), lds, c->stream, a);
+    else hipLaunchKernelGGL((k_wf_shade<kCount, false>), dim3(grid), dim3(kBlock), lds, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    return MCRT_OK;
+}
+template <bool kCount> int launch_wf_trace(mcrt_ctx* c, const WfArgs& a, uint32_t bound)
+{
+    // LDS: the SMALL image + the top of every lane's stack; the number of resident blocks follows from the stack entries kept in LDS
+    const size_t small_bytes = c->lds_bytes;
+    if (c->wf_trace_variant == 1) {
+        hipLaunchKernelGGL((k_wf_trace<kCount, 8, 8>), dim3(wf_grid((uint32_t)c->cu_count * 8u, bound)), dim3(kBlock), small_bytes + 8u * 2u * kBlock * 4u, c->stream, a);
+    } else if (c->wf_trace_variant == 2) {
+        hipLaunchKernelGGL((k_wf_trace<kCount, 18, 4>), dim3(wf_grid((uint32_t)c->cu_count * 4u, bound)), dim3(kBlock), small_bytes + 18u * 2u * kBlock * 4u, c->stream, a);
+    } else {
+        hipLaunchKernelGGL((k_wf_trace<kCount, 11, 6>), dim3(wf_grid((uint32_t)c->cu_count * 6u, bound)), dim3(kBlock), small_bytes + 11u * 2u * kBlock * 4u, c->stream, a);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return MCRT_OK;
+}
+
+// The render pass of `r` through the wavefront pipeline.  Synchronises the stream every few iterations (the host has to learn
+// when the slot queue has run empty); the accumulators are complete when it returns.
+int render_wavefront(mcrt_ctx* c, const RenderArgs& r)
+{
+    WfArgs a;
+    a.r = r;
+    a.r.pend = c->d_wf_pend;
+    a.state = c->d_wf_state; a.hits = c->d_wf_hits; a.cnt = c->d_wf_cnt; a.slots = c->wf_slots;
+    uint32_t* q[2] = { c->d_wf_queue, c->d_wf_queue + c->wf_slots };
+    HIP_TRY(c, hipMemsetAsync(c->d_wf_cnt, 0, WF_CNT_WORDS * sizeof(uint32_t), c->stream));
+    // every slot takes its first item and first camera ray
+    a.first = 1; a.q_in = nullptr; a.in_idx = WF_CNT_Q1; a.q_out = q[0]; a.out_idx = WF_CNT_Q0;
+    uint32_t bound = c->wf_slots;
+    int rc = c->counting ? launch_wf_shade<true>(c, a, bound) : launch_wf_shade<false>(c, a, bound);
+    if (rc) return rc;
+    a.first = 0;
+    uint32_t it = 0;
+    for (;; ++it) {
+        const uint32_t in = it & 1u, out = in ^ 1u;
+        a.q_in = q[in]; a.in_idx = in; a.q_out = q[out]; a.out_idx = out;
+        rc = c->counting ? launch_wf_trace<true>(c, a, bound) : launch_wf_trace<false>(c, a, bound);
+        if (rc) return rc;
+        rc = c->counting ? launch_wf_shade<true>(c, a, bound) : launch_wf_shade<false>(c, a, bound);
+        if (rc) return rc;
+        if ((it & 3u) == 3u) {
+            HIP_TRY(c, hipMemcpyAsync(c->h_wf_cnt, c->d_wf_cnt, WF_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->h_wf_cnt[out] == 0u) break;
+            bound = c->h_wf_cnt[out];
+            if (it > 4000000u) return fail(c, MCRT_ERR_STATE, "wavefront pipeline did not drain");
+        }
+    }
+    c->wf_iterations = it + 1u;
+    return MCRT_OK;
+}
+
 // Scheduling of the render kernel's lanes (LanePolicy), measured per kernel family:
 //   scan / flat / LDS-resident scenes: trace lanes batched from 36 up (profiles/r02_sweep_min_trace.txt), fetches in rounds of 64
 //   (smaller fetch groups mix tiles in a wavefront and lose 8 % and more, profiles/r02_sweep_fetch_min.txt);
@@ -1098,6 +1447,9 @@ int mcrt_create(int device_id, mcrt_ctx** out_ctx)
     if (const char* e = getenv("MCRT_LEAF_CHUNK")) { int r = atoi(e); if (r > 0 && r < (1 << 20)) c->chunk_override = r; }
     if (const char* e = getenv("MCRT_FETCH_MIN")) { int r = atoi(e); if (r >= 1 && r <= 64) c->fetch_min_override = r; }
     if (const char* e = getenv("MCRT_WAVE_SLICES")) { int r = atoi(e); if (r >= 1 && r <= 64) c->wave_slices = (uint32_t)r; }
+    if (const char* e = getenv("MCRT_WAVEFRONT")) { int r = atoi(e); if (r == 0 || r == 1) c->wavefront = r; }
+    if (const char* e = getenv("MCRT_WF_SLOTS")) { long r = atol(e); if (r >= 4096 && r <= (1l << 24)) c->wf_slots_override = (uint32_t)r; }
+    if (const char* e = getenv("MCRT_WF_TRACE")) { int r = atoi(e); if (r >= 0 && r <= 2) c->wf_trace_variant = r; }
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     c->stream = c->own_stream;
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
@@ -1128,6 +1480,12 @@ int mcrt_destroy(mcrt_ctx* c)
     if (c->d_resolve_img) (void)hipFree(c->d_resolve_img);
     if (c->d_resolve_mean) (void)hipFree(c->d_resolve_mean);
     if (c->d_pend) (void)hipFree(c->d_pend);
+    if (c->d_wf_state) (void)hipFree(c->d_wf_state);
+    if (c->d_wf_hits) (void)hipFree(c->d_wf_hits);
+    if (c->d_wf_queue) (void)hipFree(c->d_wf_queue);
+    if (c->d_wf_cnt) (void)hipFree(c->d_wf_cnt);
+    if (c->d_wf_pend) (void)hipFree(c->d_wf_pend);
+    if (c->h_wf_cnt) (void)hipHostFree(c->h_wf_cnt);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1443,7 +1801,8 @@ int mcrt_render(mcrt_ctx* c, uint32_t sample_begin, uint32_t sample_count, uint3
     if (rc) return rc;
     if (max_depth > kMaxDepthLimit) return fail(c, MCRT_ERR_LIMIT, "max_depth above 256");
     if (sample_count == 0) return MCRT_OK;
-    rc = ensure_pend(c, max_depth);
+    const bool wavefront = use_wavefront(c);
+    rc = wavefront ? ensure_wavefront(c, max_depth) : ensure_pend(c, max_depth);
     if (rc) return rc;
     HIP_TRY(c, hipMemsetAsync(c->d_tile, 0, 2 * sizeof(uint32_t), c->stream));
     if (c->counting) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
@@ -1478,7 +1837,7 @@ int mcrt_render(mcrt_ctx* c, uint32_t sample_begin, uint32_t sample_count, uint3
     }
     a.seed = seed;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    rc = launch_render(c, a);
+    rc = wavefront ? render_wavefront(c, a) : launch_render(c, a);
     if (rc) return rc;
     if (a.slices > 1) {
         const uint64_t values = (uint64_t)c->accum_pixels * 3;

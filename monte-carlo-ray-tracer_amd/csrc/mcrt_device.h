@@ -477,18 +477,19 @@ struct ScratchStack {
 // measured on the 1M-triangle scene, a scratch-only stack was most of the kernel's HBM traffic.
 constexpr int LDS_STACK_ENTRIES = 18;
 constexpr int LDS_STACK_BLOCK = 256;
-struct LdsStack {
+template <int kEntries> struct LdsStackT {
     __attribute__((address_space(3))) uint32_t* col;      // this thread's column
-    float t_[TRAVERSAL_STACK - LDS_STACK_ENTRIES];
-    uint32_t w_[TRAVERSAL_STACK - LDS_STACK_ENTRIES];
+    float t_[TRAVERSAL_STACK - kEntries];
+    uint32_t w_[TRAVERSAL_STACK - kEntries];
     MCRT_DEV void put(int i, float t, uint32_t w)
     {
-        if (i < LDS_STACK_ENTRIES) { col[(i * 2 + 0) * LDS_STACK_BLOCK] = __float_as_uint(t); col[(i * 2 + 1) * LDS_STACK_BLOCK] = w; }
-        else { t_[i - LDS_STACK_ENTRIES] = t; w_[i - LDS_STACK_ENTRIES] = w; }
+        if (i < kEntries) { col[(i * 2 + 0) * LDS_STACK_BLOCK] = __float_as_uint(t); col[(i * 2 + 1) * LDS_STACK_BLOCK] = w; }
+        else { t_[i - kEntries] = t; w_[i - kEntries] = w; }
     }
-    MCRT_DEV float t(int i) const { return i < LDS_STACK_ENTRIES ? __uint_as_float(col[(i * 2 + 0) * LDS_STACK_BLOCK]) : t_[i - LDS_STACK_ENTRIES]; }
-    MCRT_DEV uint32_t get(int i) const { return i < LDS_STACK_ENTRIES ? col[(i * 2 + 1) * LDS_STACK_BLOCK] : w_[i - LDS_STACK_ENTRIES]; }
+    MCRT_DEV float t(int i) const { return i < kEntries ? __uint_as_float(col[(i * 2 + 0) * LDS_STACK_BLOCK]) : t_[i - kEntries]; }
+    MCRT_DEV uint32_t get(int i) const { return i < kEntries ? col[(i * 2 + 1) * LDS_STACK_BLOCK] : w_[i - kEntries]; }
 };
+typedef LdsStackT<LDS_STACK_ENTRIES> LdsStack;
 
 // Reciprocal of a direction component for the slab and plane tests of the walk.  A zero (or tiny) component would give
 // +-inf, and (face - origin) * inf is NaN when the origin lies exactly on the face - min/max drop the NaN and the node
