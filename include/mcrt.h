@@ -160,6 +160,19 @@ int mcrt_set_stream(mcrt_ctx* ctx, void* hip_stream);
 int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* scene,
                       const mcrt_accel_params* accel);
 
+/* The same upload with the octree built ON THE DEVICE: for scenes edited between
+ * frames - objects moved, triangles added or removed - where rebuilding on the host
+ * (1.7 s for 10^6 triangles) would stall the render loop.  This is the build's
+ * counterpart of the reference's incremental Octree::InsertIfOverlaps / Fill
+ * (source/accelerationstructures/octree.h:50-70,77-92): after an edit the caller
+ * passes the whole edited scene again and kernels re-index it level by level (same
+ * cells, split rule, overlap tests and node numbering as the host build, so every
+ * query answers as before: the brute force of source/scene.cpp:62-80).
+ * mcrt_last_build_ms: device time of the last such build. */
+int mcrt_upload_scene_device_build(mcrt_ctx* ctx, const mcrt_scene_desc* scene,
+                                   const mcrt_accel_params* accel);
+int mcrt_last_build_ms(mcrt_ctx* ctx, float* out_ms);
+
 /* Camera::Camera + Camera::SetView, source/core/camera.h:19-34; also sizes
  * and zeroes the PixelBuffer accumulators (source/core/pixelbuffer.cpp:7-23):
  * the accumulator in use is cleared, a caller-bound one included.  When the

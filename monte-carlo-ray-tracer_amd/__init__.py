@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(HERE, "libmcrt_hip.so")
 
 # every symbol include/mcrt.h declares
 ABI_SYMBOLS = (
-    "mcrt_create", "mcrt_destroy", "mcrt_last_error", "mcrt_set_stream", "mcrt_upload_scene", "mcrt_set_camera", "mcrt_set_accel",
+    "mcrt_create", "mcrt_destroy", "mcrt_last_error", "mcrt_set_stream", "mcrt_upload_scene", "mcrt_upload_scene_device_build", "mcrt_last_build_ms", "mcrt_set_camera", "mcrt_set_accel",
     "mcrt_camera_rays", "mcrt_intersect", "mcrt_intersect_device", "mcrt_intersect_noalloc", "mcrt_trace_samples", "mcrt_trace_rays", "mcrt_render_unlit", "mcrt_rng_seed",
     "mcrt_clear", "mcrt_dropped_samples", "mcrt_bind_accumulator", "mcrt_accumulator", "mcrt_render", "mcrt_last_render_ms", "mcrt_resolve",
     "mcrt_read_accumulator", "mcrt_write_accumulator", "mcrt_synchronize", "mcrt_octree_info_get", "mcrt_octree_download", "mcrt_set_counting", "mcrt_counters",
@@ -153,9 +153,16 @@ class Backend:
     def set_stream(self, stream_handle):
         self._ck(self.lib.mcrt_set_stream(self.ctx, C.c_void_p(stream_handle)))
 
-    def upload_scene(self, flat, accel=None):
+    def upload_scene(self, flat, accel=None, device_build=False):
+        """device_build: the octree is built by kernels on the GPU (mcrt_upload_scene_device_build) instead of on the host."""
         d = flat.desc()
-        self._ck(self.lib.mcrt_upload_scene(self.ctx, C.byref(d), C.byref(accel) if accel is not None else None))
+        fn = self.lib.mcrt_upload_scene_device_build if device_build else self.lib.mcrt_upload_scene
+        self._ck(fn(self.ctx, C.byref(d), C.byref(accel) if accel is not None else None))
+
+    def last_build_ms(self):
+        ms = C.c_float()
+        self._ck(self.lib.mcrt_last_build_ms(self.ctx, C.byref(ms)))
+        return float(ms.value)
 
     def set_camera(self, cam):
         self._ck(self.lib.mcrt_set_camera(self.ctx, C.byref(cam)))

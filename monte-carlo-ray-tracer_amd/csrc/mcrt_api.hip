@@ -32,6 +32,7 @@
 #include "mcrt.h"
 #include "mcrt_device.h"
 #include "mcrt_flatten.h"
+#include "mcrt_build.h"
 
 using namespace mcrt;
 
@@ -1042,6 +1043,8 @@ struct mcrt_ctx {
     uint32_t* d_small = nullptr;
     uint32_t* d_big = nullptr;
     bool have_scene = false;
+    bool tree_on_host = true;                   // flat.node_box / node_words / refs mirror the device tree (false after a device build, until downloaded)
+    float last_build_ms = 0.0f;                 // device build: kernel time of the last one
     bool big_in_lds = false;
     size_t lds_bytes = 0;
 
@@ -1502,23 +1505,48 @@ int mcrt_set_stream(mcrt_ctx* c, void* hip_stream)
     return MCRT_OK;
 }
 
-int mcrt_upload_scene(mcrt_ctx* c, const mcrt_scene_desc* scene, const mcrt_accel_params* accel)
+namespace {
+int upload_scene_impl(mcrt_ctx* c, const mcrt_scene_desc* scene, const mcrt_accel_params* accel, bool device_build)
 {
     if (!c) return MCRT_ERR_INVALID;
     int rc = bind_device(c);
     if (rc) return rc;
     FlatScene flat;
     std::string err;
-    rc = flatten_scene(scene, accel, flat, err);
+    rc = flatten_scene(scene, accel, flat, err, !device_build);
     if (rc) return fail(c, rc, err);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->d_small) { HIP_TRY(c, hipFree(c->d_small)); c->d_small = nullptr; }
     if (c->d_big) { HIP_TRY(c, hipFree(c->d_big)); c->d_big = nullptr; }
     c->have_scene = false;
     HIP_TRY(c, hipMalloc(&c->d_small, std::max<size_t>(flat.small_img.size(), 1) * 4));
-    HIP_TRY(c, hipMalloc(&c->d_big, std::max<size_t>(flat.big_img.size(), 1) * 4));
     HIP_TRY(c, hipMemcpy(c->d_small, flat.small_img.data(), flat.small_img.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_big, flat.big_img.data(), flat.big_img.size() * 4, hipMemcpyHostToDevice));
+    if (!device_build) {
+        HIP_TRY(c, hipMalloc(&c->d_big, std::max<size_t>(flat.big_img.size(), 1) * 4));
+        HIP_TRY(c, hipMemcpy(c->d_big, flat.big_img.data(), flat.big_img.size() * 4, hipMemcpyHostToDevice));
+        c->tree_on_host = true;
+    } else {
+        // the octree is built by kernels (csrc/mcrt_build.h) from the caller's triangles and the SMALL image already on the device;
+        // the host flattener has laid out the triangle and pair records from word 0 of its big image
+        bld::Params P = { flat.view.nobj, flat.view.nprim, flat.view.ntri, flat.max_leaf, flat.max_depth, flat.stay, flat.pad_rel };
+        bld::Result R;
+        if (bld::build_on_device(c->stream, P, c->d_small, flat.view.off_obj, scene->triangle_count ? &scene->triangles[0].v0[0] : nullptr, flat.big_img,
+                                 flat.view.off_pair, R, err)) {
+            if (R.d_big) (void)hipFree(R.d_big);
+            return fail(c, MCRT_ERR_HIP, err);
+        }
+        c->d_big = R.d_big;
+        SceneView& v = flat.view;
+        v.nnode = R.nnode; v.off_node = R.off_node; v.off_leaf = R.off_leaf; v.off_tri = R.off_tri; v.tri_src = R.off_tri; v.off_pair = R.off_pair;
+        v.big_words = (uint32_t)R.big_words;
+        for (int a = 0; a < 3; ++a) v.root_size[a] = R.root_cell[3 + a] - R.root_cell[a];
+        v.walk_pad = R.pad;
+        flat.tree_depth = R.depth; flat.ref_count = R.nrefs; flat.pad = R.pad;
+        for (int a = 0; a < 6; ++a) flat.root_cell[a] = R.root_cell[a];
+        flat.big_img.clear(); flat.big_img.shrink_to_fit();
+        c->tree_on_host = false;
+        c->last_build_ms = R.build_ms;
+    }
     c->flat = std::move(flat);
     c->view = c->flat.view;
     c->view.small_img = c->d_small;
@@ -1532,6 +1560,41 @@ int mcrt_upload_scene(mcrt_ctx* c, const mcrt_scene_desc* scene, const mcrt_acce
     if (c->accel_request == MCRT_ACCEL_SCAN && !c->view.has_pairs) c->accel_request = MCRT_ACCEL_AUTO;   // scan cannot serve this scene
     if (c->accel_request == MCRT_ACCEL_FLAT && !flat_ok(c)) c->accel_request = MCRT_ACCEL_AUTO;
     resolve_accel(c);
+    return MCRT_OK;
+}
+
+// after a device build the host copies of the tree (mcrt_octree_download, introspection) are read back from the records on demand
+int ensure_tree_on_host(mcrt_ctx* c)
+{
+    if (c->tree_on_host) return MCRT_OK;
+    int rc = bind_device(c);
+    if (rc) return rc;
+    const uint32_t nn = c->view.nnode, nr = c->flat.ref_count;
+    DevBuf<float> box; DevBuf<uint32_t> words, refs;
+    HIP_TRY(c, hipMalloc(&box.p, std::max<size_t>(nn, 1) * 24)); HIP_TRY(c, hipMalloc(&words.p, std::max<size_t>(nn, 1) * 8)); HIP_TRY(c, hipMalloc(&refs.p, std::max<size_t>(nr, 1) * 4));
+    const uint32_t n = std::max(nn, nr);
+    hipLaunchKernelGGL(bld::k_bld_unpack, dim3(bld::blocks_for(n)), dim3(bld::kThreads), 0, c->stream, nn, nr, (const uint32_t*)c->d_big, c->view.off_node, c->view.off_leaf, box.p,
+                       words.p, refs.p);
+    HIP_TRY(c, hipGetLastError());
+    c->flat.node_box.resize((size_t)nn * 6); c->flat.node_words.resize((size_t)nn * 2); c->flat.refs.resize(nr);
+    HIP_TRY(c, hipMemcpyAsync(c->flat.node_box.data(), box.p, (size_t)nn * 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->flat.node_words.data(), words.p, (size_t)nn * 8, hipMemcpyDeviceToHost, c->stream));
+    if (nr) HIP_TRY(c, hipMemcpyAsync(c->flat.refs.data(), refs.p, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->tree_on_host = true;
+    return MCRT_OK;
+}
+} // namespace
+
+int mcrt_upload_scene(mcrt_ctx* c, const mcrt_scene_desc* scene, const mcrt_accel_params* accel) { return upload_scene_impl(c, scene, accel, false); }
+
+int mcrt_upload_scene_device_build(mcrt_ctx* c, const mcrt_scene_desc* scene, const mcrt_accel_params* accel) { return upload_scene_impl(c, scene, accel, true); }
+
+int mcrt_last_build_ms(mcrt_ctx* c, float* out_ms)
+{
+    if (!c || !out_ms) return MCRT_ERR_INVALID;
+    if (!c->have_scene || c->last_build_ms <= 0.0f) return fail(c, MCRT_ERR_STATE, "no scene built on the device yet");
+    *out_ms = c->last_build_ms;
     return MCRT_OK;
 }
 
@@ -2007,6 +2070,8 @@ int mcrt_octree_download(mcrt_ctx* c, float* node_box, uint32_t* node_words, uin
 {
     if (!c) return MCRT_ERR_INVALID;
     if (!c->have_scene) return fail(c, MCRT_ERR_STATE, "no scene uploaded (mcrt_upload_scene)");
+    int rc = ensure_tree_on_host(c);
+    if (rc) return rc;
     if (node_box) std::memcpy(node_box, c->flat.node_box.data(), c->flat.node_box.size() * 4);
     if (node_words) std::memcpy(node_words, c->flat.node_words.data(), c->flat.node_words.size() * 4);
     if (prim_refs) std::memcpy(prim_refs, c->flat.refs.data(), c->flat.refs.size() * 4);

@@ -258,7 +258,7 @@ void camera_look_at(uint32_t width, uint32_t height, float fov_y_degrees, const 
     out->width = width; out->height = height;
 }
 
-int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, FlatScene& out, std::string& err)
+int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, FlatScene& out, std::string& err, bool build_tree)
 {
     if (!sc || (sc->object_count && !sc->objects) || (sc->triangle_count && !sc->triangles)) { err = "null scene description"; return MCRT_ERR_INVALID; }
     if (sc->object_count == 0) { err = "scene has no objects"; return MCRT_ERR_INVALID; }
@@ -293,6 +293,17 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
     }
     const uint32_t nprim = uint32_t(prim_obj.size());
 
+    out.tree_built = build_tree;
+    out.max_leaf = (accel && accel->max_leaf_prims) ? accel->max_leaf_prims : 4u;
+    out.max_depth = (accel && accel->max_depth) ? std::min(accel->max_depth, MAX_TREE_DEPTH) : 10u;
+    out.stay = nprim > 1024u ? 4.0f : 1.0f;
+    out.pad_rel = (accel && accel->pad_rel > 0.0f) ? accel->pad_rel : 1.0e-4f;
+    uint32_t nnode = 0;
+    float pad = 0.0f;
+    float root_cell_v[6] = { 0, 0, 0, 0, 0, 0 };
+    out.node_box.clear(); out.node_words.clear(); out.refs.clear();
+    std::vector<float> node_cell;     // per flat node: cell min xyz, 2^-depth
+    if (build_tree) {
     // ---- primitive bounds ------------------------------------------------------------
     std::vector<Box> pbox(nprim);
     std::vector<TriD> ptri(nprim);
@@ -330,7 +341,7 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
     for (int a = 0; a < 3; ++a) mag = std::max(mag, std::max(std::fabs(root.mn[a]), std::fabs(root.mx[a])));
     float pad_rel = (accel && accel->pad_rel > 0.0f) ? accel->pad_rel : 1.0e-4f;
     // absolute padding: a fraction of the scene extent, never below a few hundred ulps of the largest coordinate
-    const float pad = std::max(pad_rel * std::max(extent, 1.0e-3f), 256.0f * FLT_EPSILON * mag);
+    pad = std::max(pad_rel * std::max(extent, 1.0e-3f), 256.0f * FLT_EPSILON * mag);
     for (Box& b : pbox) for (int a = 0; a < 3; ++a) { b.mn[a] -= pad; b.mx[a] += pad; }
     for (int a = 0; a < 3; ++a) { root.mn[a] -= 2.0f * pad; root.mx[a] += 2.0f * pad; }
 
@@ -343,7 +354,7 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
     if (B.pool.size() >= (1u << 24)) { err = "octree has more than 2^24 nodes"; return MCRT_ERR_LIMIT; }
 
     // ---- flatten breadth-first: children of a node are contiguous ----------------------
-    const uint32_t nnode = uint32_t(B.pool.size());
+    nnode = uint32_t(B.pool.size());
     std::vector<int> order;           // flat index -> build index
     std::vector<uint32_t> flat_of(nnode, 0);
     order.reserve(nnode);
@@ -374,15 +385,23 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
         }
     }
     out.tree_depth = B.deepest;
+    for (int a = 0; a < 3; ++a) { root_cell_v[a] = B.pool[0].cell.mn[a]; root_cell_v[3 + a] = B.pool[0].cell.mx[a]; }
+    node_cell.resize(size_t(nnode) * 4);
+    for (uint32_t f = 0; f < nnode; ++f) {
+        const BuildNode& bn = B.pool[size_t(order[f])];
+        for (int k = 0; k < 3; ++k) node_cell[size_t(f) * 4 + k] = bn.cell.mn[k];
+        node_cell[size_t(f) * 4 + 3] = std::ldexp(1.0f, -int(bn.depth));
+    }
+    } else out.tree_depth = 0;
     out.ref_count = uint32_t(out.refs.size());
-    for (int a = 0; a < 3; ++a) { out.root_cell[a] = B.pool[0].cell.mn[a]; out.root_cell[3 + a] = B.pool[0].cell.mx[a]; }
+    for (int a = 0; a < 6; ++a) out.root_cell[a] = root_cell_v[a];
     out.pad = pad;
 
     // ---- SMALL image -----------------------------------------------------------------
     SceneView& v = out.view;
     v = SceneView{};
     v.nobj = nobj; v.nlights = uint32_t(lights.size()); v.ntri = sc->triangle_count; v.nprim = nprim; v.nnode = nnode;
-    for (int a = 0; a < 3; ++a) v.root_size[a] = B.pool[0].cell.mx[a] - B.pool[0].cell.mn[a];
+    for (int a = 0; a < 3; ++a) v.root_size[a] = root_cell_v[3 + a] - root_cell_v[a];
     v.walk_pad = pad;
     v.off_obj = 0;
     v.off_lights = v.off_obj + nobj * OBJ_STRIDE;
@@ -429,7 +448,7 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
     // ---- BIG image -------------------------------------------------------------------
     uint64_t off = 0;
     v.off_node = uint32_t(off);      off += uint64_t(nnode) * NODE_STRIDE;
-    v.off_leaf = uint32_t(off);      off += (uint64_t(out.refs.size()) + 1u) * LEAF_STRIDE;   // +1: the traversal prefetches one record ahead
+    v.off_leaf = uint32_t(off);      if (build_tree) off += (uint64_t(out.refs.size()) + 1u) * LEAF_STRIDE;   // +1: the traversal prefetches one record ahead
     v.off_tri = uint32_t(off);       off += uint64_t(sc->triangle_count) * TRI_STRIDE;
     v.tri_src = v.off_tri;
     // triangle-pair records for the scan path: only built for scenes it can be chosen for
@@ -451,9 +470,7 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
         for (uint32_t k = 0; k < 6; ++k) w[NODE_BOX + k] = fbits(out.node_box[size_t(f) * 6 + k]);
         w[NODE_CHILD] = out.node_words[size_t(f) * 2];
         w[NODE_LEAF] = out.node_words[size_t(f) * 2 + 1];
-        const BuildNode& bn = B.pool[size_t(order[f])];
-        for (uint32_t k = 0; k < 3; ++k) w[NODE_CELL + k] = fbits(bn.cell.mn[k]);
-        w[NODE_SCALE] = fbits(std::ldexp(1.0f, -int(bn.depth)));
+        for (uint32_t k = 0; k < 4; ++k) w[NODE_CELL + k] = fbits(node_cell[size_t(f) * 4 + k]);
     }
     for (uint32_t t = 0; t < sc->triangle_count; ++t) {
         const mcrt_triangle& tr = sc->triangles[t];

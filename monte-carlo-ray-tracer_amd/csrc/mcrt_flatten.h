@@ -22,10 +22,15 @@ struct FlatScene {
     std::vector<uint32_t> refs;
     float root_cell[6] = { 0, 0, 0, 0, 0, 0 };   // min xyz, max xyz of the root cell
     float pad = 0.0f;
+    // build_tree == false (the octree is built on the device, csrc/mcrt_build.h): big_img holds only the triangle and pair
+    // records, laid out from word 0 (view.off_tri == 0), and these are the builder's parameters as the host would use them
+    bool tree_built = true;
+    uint32_t max_leaf = 4, max_depth = 10;
+    float stay = 1.0f, pad_rel = 1.0e-4f;
 };
 
 // Returns MCRT_OK or an MCRT_ERR_* code with `err` set.
-int flatten_scene(const mcrt_scene_desc* scene, const mcrt_accel_params* accel, FlatScene& out, std::string& err);
+int flatten_scene(const mcrt_scene_desc* scene, const mcrt_accel_params* accel, FlatScene& out, std::string& err, bool build_tree = true);
 
 // Camera::Camera + Camera::SetView (source/core/camera.h:19-34) with glm's operation order.
 void camera_look_at(uint32_t width, uint32_t height, float fov_y_degrees, const float position[3], const float look_at[3],

@@ -10,7 +10,7 @@
 // Usage: mcrt_render [--scene cornell|hexagon] [--width W] [--height H] [--spp N] [--pass P]
 //                    [--depth D] [--seed S] [--tonemap reinhard|exposure|none] [--gamma G]
 //                    [--exposure E] [--point-light] [--obj FILE x y z] [--unlit] [--device I]
-//                    [--devices I,J,...] [--random-pixels N [--pick-seed S]]
+//                    [--devices I,J,...] [--random-pixels N [--pick-seed S]] [--device-build]
 //                    [--out image.ppm] [--raw accum.f64] [--checkpoint FILE] [--resume FILE]
 //
 // --devices I,J,...  one context and one host thread per listed GPU.  Every pass of P samples per pixel is split
@@ -120,7 +120,7 @@ int main(int argc, char** argv)
     uint64_t seed = 0x5EED0001ull, pickSeed = 1, randomPixels = 0;
     double gamma = 2.2, exposure = 1.0;                                     // main.cpp:47-48
     float objPos[3] = { 0, 0, 0 };
-    bool pointLight = false, unlit = false;
+    bool pointLight = false, unlit = false, deviceBuild = false;
     std::vector<int> devices;
     for (int i = 1; i < argc; ++i) {
         auto next = [&](const char* flag) -> const char* {
@@ -155,6 +155,7 @@ int main(int argc, char** argv)
         else if (a == "--checkpoint") checkpoint = next("--checkpoint");
         else if (a == "--resume") resume = next("--resume");
         else if (a == "--point-light") pointLight = true;
+        else if (a == "--device-build") deviceBuild = true;
         else if (a == "--unlit") unlit = true;
         else if (a == "--obj") { objPath = next("--obj"); for (float& v : objPos) v = float(std::atof(next("--obj"))); }
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -198,6 +199,7 @@ int main(int argc, char** argv)
             if (!mesh->LoadMesh(objPath)) return 1;
         }
         scene->UseDevice(devices[r]);
+        scene->octree.buildOnDevice = deviceBuild;
         scene->PrepareForRayTracing();
         if (!scene->Context()) return 1;
     }

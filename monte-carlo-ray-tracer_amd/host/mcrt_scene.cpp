@@ -211,8 +211,9 @@ Ray Camera::GetPixelRay(float x, float y) const
 
 void Octree::PrintDebug() const
 {
-    std::printf("octree: %u nodes, %u primitive references, depth %u, %s\r\n", nodeCount, primitiveRefs, depth,
-                ldsResident ? "LDS resident" : "read through L2");
+    std::printf("octree: %u nodes, %u primitive references, depth %u, %s", nodeCount, primitiveRefs, depth, ldsResident ? "LDS resident" : "read through L2");
+    if (buildOnDevice) std::printf(", built on the device in %.2f ms", lastBuildMs);
+    std::printf("\r\n");
 }
 
 // ---------------------------------------------------------------------- scene
@@ -298,7 +299,8 @@ void Scene::PrepareForRayTracing()
     Flatten(desc);
     if (!EnsureContext()) return;
     mcrt_accel_params accel = { octree.maxCount, octree.maxDepth, 0.0f };
-    if (mcrt_upload_scene(ctx, &desc, &accel) != MCRT_OK) { Fail("upload_scene"); return; }
+    if ((octree.buildOnDevice ? mcrt_upload_scene_device_build(ctx, &desc, &accel) : mcrt_upload_scene(ctx, &desc, &accel)) != MCRT_OK) { Fail("upload_scene"); return; }
+    if (octree.buildOnDevice) mcrt_last_build_ms(ctx, &octree.lastBuildMs);
     mcrt_octree_info info;
     if (mcrt_octree_info_get(ctx, &info) == MCRT_OK) {
         octree.nodeCount = info.node_count; octree.primitiveRefs = info.prim_ref_count;

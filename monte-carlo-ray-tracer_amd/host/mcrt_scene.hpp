@@ -179,6 +179,10 @@ class Octree {
 public:
     unsigned int maxCount = 0;         // 0 = library default
     unsigned int maxDepth = 0;
+    // true: PrepareForRayTracing has the GPU build the tree (mcrt_upload_scene_device_build) - for scenes edited between frames,
+    // what the reference's incremental InsertIfOverlaps is for (octree.h:50-70): edit the objects, call PrepareForRayTracing again
+    bool buildOnDevice = false;
+    float lastBuildMs = 0.0f;          // device time of the last device build
     AABB aabb;                         // root box after Fill
     unsigned int nodeCount = 0, primitiveRefs = 0, depth = 0;
     bool ldsResident = false;

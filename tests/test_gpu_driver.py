@@ -276,3 +276,120 @@ def test_config4_image_size_on_the_million_triangle_scene(backend, pkg, oracle, 
     _check_pixels(backend, oracle, sc, cam, spp, a, px)
     backend.upload_scene(scene_of("cornell"))
     backend.set_camera(oracle.camera(64, 64, 90.0, POS, TGT))
+
+
+# ------------------------------------------------------------------ the octree built on the device
+def _lists(words, refs):
+    """Per node: the sorted primitive ids of its list."""
+    out = []
+    for cw, first in words:
+        if first == 0xFFFFFFFF:
+            out.append(())
+            continue
+        k = int(first)
+        while not refs[k] & 0x80000000:
+            k += 1
+        out.append(tuple(sorted(int(r) & 0x7FFFFFFF for r in refs[int(first):k + 1])))
+    return out
+
+
+@pytest.mark.parametrize("name", ["cornell", "config2", "config3", "config4_2k", "hexagon", "cornell_point", "cornell_sphere_light"])
+def test_device_built_octree_is_the_host_built_one(backend, pkg, oracle, po, scene_of, golden, name):
+    """mcrt_upload_scene_device_build: the kernels produce the host builder's tree node for node (boxes, child words, cells; lists
+    equal as sets), the reference's fixture rays hit the same (object, element, t) through it, and the CPU replay of the
+    downloaded tree equals the fixtures too."""
+    flat = scene_of(name)
+    g = golden(f"hits_{name}.npz")
+    sc = oracle.scene(flat)
+    for accel in (None, pkg.AccelParams(1, 12, 0.0), pkg.AccelParams(16, 2, 0.0), pkg.AccelParams(2, 6, 1e-6)):
+        hinfo, hbox, hwords, hrefs = pkg.build_scene_image(flat, accel)
+        backend.upload_scene(flat, accel, device_build=True)
+        info = backend.octree_info()
+        assert (info.node_count, info.prim_ref_count, info.prim_count, info.max_depth) == (hinfo.node_count, hinfo.prim_ref_count, hinfo.prim_count, hinfo.max_depth)
+        assert list(info.root_cell_min) == list(hinfo.root_cell_min) and list(info.root_cell_max) == list(hinfo.root_cell_max) and info.pad == hinfo.pad
+        box, words, refs = backend.octree_download()
+        assert np.array_equal(box.view(np.uint32), hbox.view(np.uint32))
+        assert np.array_equal(words[:, 0], hwords[:, 0])
+        assert _lists(words, refs) == _lists(hwords, hrefs)
+        backend.set_accel(pkg.ACCEL_OCTREE)
+        obj, elem, t = backend.intersect(g["origins"], g["dirs"])
+        backend.set_accel(pkg.ACCEL_AUTO)
+        assert np.array_equal(obj, g["obj"]) and np.array_equal(elem, g["elem"]) and np.array_equal(t.view(np.uint32), g["t"].view(np.uint32))
+        wobj, welem, wt = oracle.intersect_octree(sc, info, box, words, refs, g["origins"][:5000], g["dirs"][:5000])
+        assert np.array_equal(wobj, g["obj"][:5000]) and np.array_equal(welem, g["elem"][:5000]) and np.array_equal(wt, g["t"][:5000])
+
+
+def test_device_rebuild_after_an_edit(backend, pkg, oracle, scene_of, golden):
+    """A scene edited between frames (a box moved, the 2000-triangle mesh sheared): re-indexed on the device, every query answers
+    as the brute force over the EDITED scene does, and a render through it equals the render through a host-built tree."""
+    flat = scene_of("config4_2k")
+    g = golden("hits_config4_2k.npz")
+    cam = oracle.camera(64, 48, 90.0, POS, TGT)
+    backend.upload_scene(flat, device_build=True)
+    rng = np.random.default_rng(21)
+    for step in range(3):
+        edited = pkg.FlatScene(flat.objects.copy(), flat.triangles.copy(), flat.background)
+        big = int(np.argmax(edited.objects["triangle_count"]))
+        o = edited.objects[big]
+        sl = slice(int(o["first_triangle"]), int(o["first_triangle"]) + int(o["triangle_count"]))
+        shift = rng.uniform(-0.6, 0.6, 3).astype(np.float32) * (step + 1)
+        tri = edited.triangles[sl]
+        for f in ("v0", "v1", "v2"):
+            tri[f] = (tri[f] + shift).astype(np.float32)
+            tri[f][:, 0] += np.float32(0.1 * step) * tri[f][:, 1]                       # shear
+        e1, e2 = tri["v1"] - tri["v0"], tri["v2"] - tri["v0"]
+        n = np.cross(e1, e2).astype(np.float32)
+        tri["normal"] = (n / np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-30)).astype(np.float32)
+        edited.triangles[sl] = tri
+        verts = np.concatenate([tri["v0"], tri["v1"], tri["v2"], edited.objects["position"][big][None, :]])
+        edited.objects["aabb_min"][big] = verts.min(axis=0)                             # TriangleMesh::UpdateAABB starts from `position`
+        edited.objects["aabb_max"][big] = verts.max(axis=0)
+        backend.upload_scene(edited, device_build=True)
+        assert backend.last_build_ms() > 0.0
+        sc = oracle.scene(edited)
+        backend.set_accel(pkg.ACCEL_OCTREE)
+        obj, elem, t = backend.intersect(g["origins"][:20000], g["dirs"][:20000])
+        wobj, welem, wt = oracle.intersect(sc, g["origins"][:20000], g["dirs"][:20000])                # brute force
+        assert np.array_equal(obj, wobj) and np.array_equal(elem, welem) and np.array_equal(t.view(np.uint32), wt.view(np.uint32))
+        backend.set_camera(cam)
+        backend.clear(); backend.render(0, 6, 100, SEED)
+        a = backend.read_accumulator()
+        backend.upload_scene(edited)                                                    # host build of the same scene
+        backend.set_accel(pkg.ACCEL_OCTREE)
+        backend.set_camera(cam)
+        backend.clear(); backend.render(0, 6, 100, SEED)
+        assert np.array_equal(a, backend.read_accumulator())
+        backend.set_accel(pkg.ACCEL_AUTO)
+
+
+def test_device_build_of_the_million_triangle_scene(backend, pkg, oracle, scene_of):
+    """BASELINE config 4's geometry indexed on the device: the host builder's node and reference counts, hits equal the oracle's
+    brute force over all 1,000,012 triangles, per-sample radiance equal to the oracle's."""
+    import time
+
+    from mcrt_amd import scenes
+
+    flat = scenes.config4(scene_of("cornell"), n=1_000_000, seed=42)
+    t0 = time.perf_counter()
+    backend.upload_scene(flat, device_build=True)
+    wall = time.perf_counter() - t0
+    info = backend.octree_info()
+    hinfo, _, _, _ = pkg.build_scene_image(flat)
+    print(f"device build: {backend.last_build_ms():.1f} ms of kernels, {wall * 1e3:.0f} ms wall for {info.prim_count} primitives -> {info.node_count} nodes, {info.prim_ref_count} references")
+    assert (info.node_count, info.prim_ref_count, info.max_depth) == (hinfo.node_count, hinfo.prim_ref_count, hinfo.max_depth)
+    sc = oracle.scene(flat)
+    rng = np.random.default_rng(9)
+    o = rng.uniform(-4.4, 4.4, (300, 3)).astype(np.float32)
+    d = rng.normal(size=(300, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    obj, elem, t = backend.intersect(o, d)
+    wobj, welem, wt = oracle.intersect(sc, o, d)
+    assert np.array_equal(obj, wobj) and np.array_equal(elem, welem) and np.array_equal(t.view(np.uint32), wt.view(np.uint32))
+    cam = oracle.camera(64, 64, 90.0, POS, TGT)
+    backend.set_camera(cam)
+    px = rng.integers(0, 64 * 64, 40).astype(np.uint32)
+    sm = rng.integers(0, 1000, 40).astype(np.uint32)
+    got = backend.trace_samples(px, sm, SEED, 100)
+    want = oracle.trace_samples(sc, cam, px, sm, SEED, 100, portable_math=True, forward_sum=True)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    backend.upload_scene(scene_of("cornell"))
