@@ -485,7 +485,7 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
             }
             if constexpr (kWalk) {
                 // a lane without a ray has an empty stack: it sits in the walk loop as a finished lane
-                if (live && !walking) { walk.begin(big, v, walk_stack, cn); walking = true; }
+                if (live && !walking) { walk.begin(sm, v, walk_stack, ln.ro, ln.rd, cn); walking = true; }
                 walk.run(sm, big, v, walk_stack, ln.ro, ln.rd, cn, policy.refill & 0xFFu, policy.refill >> 8);
                 if (!live || !walk.done()) continue;          // no ray, or still in mid-traversal: nothing to shade yet
                 walking = false;
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(kBlock, kBlocksPerCu) void k_wf_trace(const WfArgs 
     // (measured: 2 M rays took 12 ms of which the atomics were most).
     uint32_t w_pos = 0, w_end = 0;
     for (;;) {
-        const bool idle_lane = walk.sp == 0;
+        const bool idle_lane = walk.done();
         if (idle_lane && slot != WF_NONE) {
             a.hits[slot] = u4(walk.best.prim, walk.best.obj, walk.best.elem, __float_as_uint(walk.best.t));
             slot = WF_NONE;
@@ -819,14 +819,14 @@ __global__ __launch_bounds__(kBlock, kBlocksPerCu) void k_wf_trace(const WfArgs 
                 inv = mk(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
                 padt = mk(v.walk_pad * fabsf(inv.x), v.walk_pad * fabsf(inv.y), v.walk_pad * fabsf(inv.z));
                 flip = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
-                walk.begin(big, v, st, cn);
+                walk.begin(sm, v, st, o, d, cn);
             }
             const uint32_t taken = (uint32_t)__popcll(need) < avail ? (uint32_t)__popcll(need) : avail;
             w_pos += taken;
             need = __ballot(mine && !take);
         }
-        if (__ballot(walk.sp > 0) == 0ull) break;     // nobody walks: every lane has stored its hit and found the queue empty
-        if (walk.sp > 0) walk.visit(sm, nodes, leaves, v, st, o, d, inv, padt, flip, 4u, cn);
+        if (__ballot(!walk.done()) == 0ull) break;     // nobody walks: every lane has stored its hit and found the queue empty
+        if (!walk.done()) walk.visit(sm, nodes, leaves, v, st, o, d, inv, padt, flip, 4u, cn);
     }
     if (kCount) flush_counters(a.r.counters, cn, rc);
 }
@@ -1144,9 +1144,13 @@ void resolve_accel(mcrt_ctx* c)
 // 4 wavefronts per SIMD, 4 workgroups per CU; more would only queue behind them (and double the parked-branch stack)
 uint32_t grid_for(const mcrt_ctx* c) { return (uint32_t)c->cu_count * c->grid_mult; }
 
+bool scene_has_refractive(const mcrt_ctx* c);
+// The parked-branch stacks: one 64-byte line per (launched lane, entry), max_depth entries per lane - a refractive split parks one
+// branch and both branches are one level deeper, so max_depth bounds the stack (source/scene.cpp:209-214).  1.7 GB at the reference's
+// depth of 100 with 262144 launched lanes; a scene without refractive surfaces never parks anything and gets no stacks.
 int ensure_pend(mcrt_ctx* c, uint32_t max_depth)
 {
-    const uint32_t entries = std::max(1u, max_depth);
+    const uint32_t entries = scene_has_refractive(c) ? std::max(1u, max_depth) : 1u;
     const size_t lanes = (size_t)grid_for(c) * kBlock;
     const size_t words = lanes * kPendFields * entries;
     if (words > c->pend_words) {

@@ -470,6 +470,8 @@ struct ScratchStack {
     MCRT_DEV void put(int i, float t, uint32_t w) { t_[i] = t; w_[i] = w; }
     MCRT_DEV float t(int i) const { return t_[i]; }
     MCRT_DEV uint32_t get(int i) const { return w_[i]; }
+    MCRT_DEV bool room(int, int) const { return false; }
+    MCRT_DEV void put_fast(int i, float t, uint32_t w) { put(i, t, w); }
 };
 // The first LDS_STACK_ENTRIES entries live in LDS (field-major, one dword column per thread of the 256-thread
 // block: bank = thread id, conflict-free whatever the lanes' stack depths), the rest in scratch memory.  Scratch
@@ -488,6 +490,9 @@ template <int kEntries> struct LdsStackT {
     }
     MCRT_DEV float t(int i) const { return i < kEntries ? __uint_as_float(col[(i * 2 + 0) * LDS_STACK_BLOCK]) : t_[i - kEntries]; }
     MCRT_DEV uint32_t get(int i) const { return i < kEntries ? col[(i * 2 + 1) * LDS_STACK_BLOCK] : w_[i - kEntries]; }
+    // entries [i, i + n) all live in LDS: put_fast needs no check (one test per visit instead of one per push)
+    MCRT_DEV bool room(int i, int n) const { return i + n <= kEntries; }
+    MCRT_DEV void put_fast(int i, float t, uint32_t w) { col[(i * 2 + 0) * LDS_STACK_BLOCK] = __float_as_uint(t); col[(i * 2 + 1) * LDS_STACK_BLOCK] = w; }
 };
 typedef LdsStackT<LDS_STACK_ENTRIES> LdsStack;
 
@@ -507,36 +512,62 @@ MCRT_DEV float slab_rcp(float d)
 template <class PS, class PB, bool kCount> struct OctreeWalk {
     Hit best;
     uint64_t gate_known, gate_pass;
-    int sp;               // entries on the stack; 0: the ray is finished, `best` is its answer
+    int sp;               // entries on the stack
+    uint32_t pleaf;       // next record of the leaf list the lane is working off, NO_REFS: none
 
-    MCRT_DEV bool done() const { return sp == 0; }
-    MCRT_DEV void idle() { sp = 0; gate_known = gate_pass = 0; best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax; }
+    MCRT_DEV bool done() const { return sp == 0 && pleaf == NO_REFS; }      // the ray is finished, `best` is its answer
+    MCRT_DEV void idle() { sp = 0; pleaf = NO_REFS; gate_known = gate_pass = 0; best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax; }
 
-    template <class St> MCRT_DEV void begin(PB, const SceneView&, St& st, Counters& cn)
+    // Scenes with at most this many objects have every mesh gate evaluated when the ray starts - by all the lanes that start together -
+    // instead of on first contact: evaluated lazily, about one lane of the wavefront meets a new mesh in every step, and the whole
+    // wavefront sits through the six IEEE divisions of the gate for it (measured on the 5-object 1M-triangle scene: 15 % of a step).
+    static constexpr uint32_t kEagerGates = 8;
+    template <class St> MCRT_DEV void begin(PS sm, const SceneView& v, St& st, V3 o, V3 d, Counters& cn)
     {
         best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax;
         if (kCount) cn.rays++;
         gate_known = 0; gate_pass = 0;
+        if (v.nobj <= kEagerGates) {
+            for (uint32_t i = 0; i < v.nobj; ++i) {
+                const uint32_t orec = v.off_obj + i * OBJ_STRIDE;
+                if (sm[orec + OBJ_KIND] == (uint32_t)MCRT_OBJECT_SPHERE) continue;
+                if (kCount) cn.gates++;
+                if (gate_hit(sm, orec, o, d)) gate_pass |= 1ull << i;
+            }
+            gate_known = ~0ull;
+        }
+        pleaf = NO_REFS;
         st.put(0, 0.0f, 0u); sp = 1;          // the root
     }
 
-    // One node visit.  inv: clamped reciprocals of the direction; padt = pad * |inv| per axis; flip: bit a set where the ray runs
+    // One step of the walk, the same two pieces of code for every lane of the wavefront:
+    //   node step   (lanes that are not in the middle of a leaf list) pop, fetch the node's record, test its tight box, push the
+    //               octants the ray passes; the node's own list, if any, becomes the lane's leaf list;
+    //   leaf step   (lanes with a leaf list, the ones that just got theirs included) ONE record: fetch, test, advance.
+    // A lane with a long list stays in leaf steps and does not pop meanwhile, so per ray the order of events is that of a
+    // sequential walk; the wavefront, though, never sits through the longest list among its 64 nodes: a step costs one node
+    // step plus one record whatever the lists look like (the chunked list loop it replaces ran at 13-17 of 64 lanes).
+    // inv: clamped reciprocals of the direction; padt = pad * |inv| per axis; flip: bit a set where the ray runs
     // towards smaller coordinates on axis a (sign of inv, so that +-0 components are treated consistently).
     template <class St> MCRT_DEV void visit(PS sm, PB nodes, PB leaves, const SceneView& v, St& st, V3 o, V3 d, V3 inv, V3 padt, uint32_t flip,
-                        uint32_t chunk, Counters& cn)
+                        uint32_t, Counters& cn)
     {
-        // next entry that was not entered behind the best hit so far
-        float t_in;
-        do {
-            if (sp == 0) return;
-            --sp;
-            t_in = st.t(sp);
-        } while (t_in > best.t);
-        const uint32_t w = st.get(sp);
-        uint32_t leaf;
-        if (w & LEAF_RESUME) leaf = w & ~LEAF_RESUME;          // the rest of a list whose node was visited before
-        else {
-            const uint32_t rec = w * NODE_STRIDE;
+        U4 a, b, c;
+        bool loaded = false;
+        if (pleaf != NO_REFS) {
+            // in the middle of a list: request the record now, the node steps of the other lanes run while it travels
+            const uint32_t r = pleaf * LEAF_STRIDE;
+            a = ld4(leaves, r); b = ld4(leaves, r + 4); c = ld4(leaves, r + 8);
+            loaded = true;
+        } else {
+            // next entry that was not entered behind the best hit so far
+            float t_in;
+            do {
+                if (sp == 0) return;
+                --sp;
+                t_in = st.t(sp);
+            } while (t_in > best.t);
+            const uint32_t rec = st.get(sp) * NODE_STRIDE;
             const U4 ra = ld4(nodes, rec), rb = ld4(nodes, rec + 4), rc = ld4(nodes, rec + 8);
             // all three loads in one round trip: without this the compiler sinks the third into the `mask != 0` branch, behind the tight test
             asm volatile("" ::"v"(rc.x), "v"(rc.y), "v"(rc.z), "v"(rc.w));
@@ -552,7 +583,7 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
                 t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
                 if (!(t0 <= t1)) return;
             }
-            leaf = rb.w;
+            pleaf = rb.w;
             const uint32_t cw = rb.z, mask = cw >> 24;
             if (mask) {
                 const uint32_t base = cw & 0x00FFFFFFu;
@@ -562,69 +593,67 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
                 const float cmn[3] = { __uint_as_float(rc.x), __uint_as_float(rc.y), __uint_as_float(rc.z) };
                 const float oo[3] = { o.x, o.y, o.z }, ii[3] = { inv.x, inv.y, inv.z }, pp[3] = { padt.x, padt.y, padt.z };
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const float size = v.root_size[a] * scale;
-                    const float mid = cmn[a] + 0.5f * size, cmx = cmn[a] + size;
-                    const bool back = (flip >> a) & 1u;
-                    const float tn = ((back ? cmx : cmn[a]) - oo[a]) * ii[a];
-                    const float tm = (mid - oo[a]) * ii[a];
-                    const float tf = ((back ? cmn[a] : cmx) - oo[a]) * ii[a];
-                    n_in[a] = tn - pp[a]; n_out[a] = tm + pp[a];
-                    f_in[a] = tm - pp[a]; f_out[a] = tf + pp[a];
+                for (int k = 0; k < 3; ++k) {
+                    const float size = v.root_size[k] * scale;
+                    const float mid = cmn[k] + 0.5f * size, cmx = cmn[k] + size;
+                    const bool back = (flip >> k) & 1u;
+                    const float tn = ((back ? cmx : cmn[k]) - oo[k]) * ii[k];
+                    const float tm = (mid - oo[k]) * ii[k];
+                    const float tf = ((back ? cmn[k] : cmx) - oo[k]) * ii[k];
+                    n_in[k] = tn - pp[k]; n_out[k] = tm + pp[k];
+                    f_in[k] = tm - pp[k]; f_out[k] = tf + pp[k];
                 }
                 // octants in ray order: bit a of k clear = the half the ray meets first on axis a; far octants are pushed first
+                const bool fast = st.room(sp, 8);
 #pragma unroll
                 for (int k = 7; k >= 0; --k) {
                     const float t0 = fmaxf(fmaxf((k & 1) ? f_in[0] : n_in[0], (k & 2) ? f_in[1] : n_in[1]), fmaxf((k & 4) ? f_in[2] : n_in[2], 0.0f));
                     const float t1 = fminf(fminf((k & 1) ? f_out[0] : n_out[0], (k & 2) ? f_out[1] : n_out[1]), fminf((k & 4) ? f_out[2] : n_out[2], best.t));
                     const uint32_t oct = (uint32_t)k ^ flip;
-                    if (((mask >> oct) & 1u) && t0 <= t1) { st.put(sp, t0, base + __popc(mask & ((1u << oct) - 1u))); ++sp; }
+                    if (((mask >> oct) & 1u) && t0 <= t1) {
+                        const uint32_t child = base + __popc(mask & ((1u << oct) - 1u));
+                        if (fast) st.put_fast(sp, t0, child); else st.put(sp, t0, child);
+                        ++sp;
+                    }
                 }
             }
         }
 
-        if (leaf != NO_REFS) {
-            // At most `chunk` records per visit: a lane with a long list re-queues the rest of it on top of its stack.
-            uint32_t r = leaf * LEAF_STRIDE;
-            U4 a = ld4(leaves, r), b = ld4(leaves, r + 4), c = ld4(leaves, r + 8);
-            bool finished = false;
-            for (uint32_t n = 0; n < chunk; ++n) {
-                r += LEAF_STRIDE;
-                // the next record of the stream is requested before this one is tested (the array ends in a pad record)
-                const U4 na = ld4(leaves, r), nb = ld4(leaves, r + 4), nc = ld4(leaves, r + 8);
-                const uint32_t prim = c.y & ~REF_LAST;
-                const uint32_t obj = c.z & ~LEAF_SPHERE;
-                const uint32_t orec = v.off_obj + obj * OBJ_STRIDE;
-                float t;
-                bool h;
-                if (c.z & LEAF_SPHERE) {
-                    if (kCount) cn.spheres++;
-                    h = sphere_hit(sm, orec, o, d, t);
-                } else {
-                    // mesh gate, evaluated once per (ray, mesh) on first contact
-                    const uint64_t bit = 1ull << obj;
-                    if (!(gate_known & bit)) {
-                        if (kCount) cn.gates++;
-                        gate_known |= bit;
-                        if (gate_hit(sm, orec, o, d)) gate_pass |= bit;
-                    }
-                    h = false;
-                    if (gate_pass & bit) {
-                        if (kCount) cn.tris++;
-                        TriRec tr;
-                        tr.v0 = mk(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
-                        tr.e1 = mk(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
-                        tr.e2 = mk(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x));
-                        h = tri_hit_rec(tr, o, d, t);
-                    }
-                }
-                if (h && nearer(t, prim, best)) {
-                    best.prim = prim; best.obj = obj; best.elem = prim - sm[orec + OBJ_FIRST_PRIM]; best.t = t;
-                }
-                if (c.y & REF_LAST) { finished = true; break; }
-                a = na; b = nb; c = nc;
+        if (pleaf != NO_REFS) {
+            if (!loaded) {
+                const uint32_t r = pleaf * LEAF_STRIDE;
+                a = ld4(leaves, r); b = ld4(leaves, r + 4); c = ld4(leaves, r + 8);
             }
-            if (!finished) { st.put(sp, t_in, (leaf + chunk) | LEAF_RESUME); ++sp; }
+            const uint32_t prim = c.y & ~REF_LAST;
+            const uint32_t obj = c.z & ~LEAF_SPHERE;
+            const uint32_t orec = v.off_obj + obj * OBJ_STRIDE;
+            float t;
+            bool h;
+            if (c.z & LEAF_SPHERE) {
+                if (kCount) cn.spheres++;
+                h = sphere_hit(sm, orec, o, d, t);
+            } else {
+                // mesh gate, evaluated once per (ray, mesh) on first contact
+                const uint64_t bit = 1ull << obj;
+                if (!(gate_known & bit)) {
+                    if (kCount) cn.gates++;
+                    gate_known |= bit;
+                    if (gate_hit(sm, orec, o, d)) gate_pass |= bit;
+                }
+                h = false;
+                if (gate_pass & bit) {
+                    if (kCount) cn.tris++;
+                    TriRec tr;
+                    tr.v0 = mk(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+                    tr.e1 = mk(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
+                    tr.e2 = mk(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x));
+                    h = tri_hit_rec(tr, o, d, t);
+                }
+            }
+            if (h && nearer(t, prim, best)) {
+                best.prim = prim; best.obj = obj; best.elem = prim - sm[orec + OBJ_FIRST_PRIM]; best.t = t;
+            }
+            pleaf = (c.y & REF_LAST) ? NO_REFS : pleaf + 1u;
         }
     }
 
@@ -638,12 +667,12 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
         const uint32_t flip = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
         const PB nodes = big + v.off_node;
         const PB leaves = big + v.off_leaf;
-        const uint32_t entered = (uint32_t)__popcll(__ballot(sp > 0));
+        const uint32_t entered = (uint32_t)__popcll(__ballot(!done()));
         const uint32_t keep = (entered * refill + 63u) / 64u;    // leave when fewer than this many are walking
         for (;;) {
-            const uint32_t walking = (uint32_t)__popcll(__ballot(sp > 0));
+            const uint32_t walking = (uint32_t)__popcll(__ballot(!done()));
             if (walking == 0 || walking < keep) break;
-            if (sp > 0) visit(sm, nodes, leaves, v, st, o, d, inv, padt, flip, chunk, cn);
+            if (!done()) visit(sm, nodes, leaves, v, st, o, d, inv, padt, flip, chunk, cn);
         }
     }
 };
@@ -653,7 +682,7 @@ MCRT_DEV Hit cast_octree(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters
 {
     OctreeWalk<PS, PB, kCount> w;
     ScratchStack st;
-    w.begin(big, v, st, cn);
+    w.begin(sm, v, st, o, d, cn);
     w.run(sm, big, v, st, o, d, cn, 0u);
     return w.best;
 }
