@@ -534,29 +534,30 @@ void HexagonScene::AddExampleLight(ColorDbl lightColor, bool usePoint)
     AddLightAt(*this, vec3{ 0.0f, 5.0f - 0.001f, 8.0f }, vec2{ 1.0f, 1.0f }, lightColor, usePoint);
 }
 
-// CornellBoxScene, source/scene.cpp:370-503
+// CornellBoxScene, source/scene.cpp:370-503.  The room as data: eight corners (index = 4 * floor + corner, corners 0..3 run
+// round the ceiling from (-w, +h, +l)) and five quads over them; object order - left wall, right wall, the white mesh - is the
+// reference's (it is the tie-break order of the nearest hit).
 CornellBoxScene::CornellBoxScene(float length, float width, float height)
 {
     halfLength = length / 2.0f;
     halfWidth = width / 2.0f;
     halfHeight = height / 2.0f;
-    leftWall = CreateObject<TriangleMesh>();
-    rightWall = CreateObject<TriangleMesh>();
-    whiteSegments = CreateObject<TriangleMesh>();
-    leftWall->material.color = ColorDbl(0.2, 0.01, 0.01);
-    rightWall->material.color = ColorDbl(0.01, 0.2, 0.01);
-    whiteSegments->material.color = ColorDbl(0.2);
-
-    const vec3 c1{ -halfWidth, halfHeight, halfLength }, c2{ halfWidth, halfHeight, halfLength };
-    const vec3 c3{ halfWidth, halfHeight, -halfLength }, c4{ -halfWidth, halfHeight, -halfLength };
-    vec3 f1 = c1, f2 = c2, f3 = c3, f4 = c4;
-    f1.y *= -1.0f; f2.y *= -1.0f; f3.y *= -1.0f; f4.y *= -1.0f;
-
-    leftWall->AddQuad(f2, c2, c3, f3);
-    rightWall->AddQuad(f1, f4, c4, c1);
-    whiteSegments->AddQuad(c4, c3, c2, c1);   // ceiling
-    whiteSegments->AddQuad(f4, f3, c3, c4);   // back wall
-    whiteSegments->AddQuad(f1, f2, f3, f4);   // floor
+    vec3 corner[8];
+    const float sx[4] = { -1.0f, 1.0f, 1.0f, -1.0f }, sz[4] = { 1.0f, 1.0f, -1.0f, -1.0f };
+    for (int k = 0; k < 4; ++k) {
+        corner[k] = vec3(sx[k] * halfWidth, halfHeight, sz[k] * halfLength);
+        corner[4 + k] = corner[k];
+        corner[4 + k].y *= -1.0f;                     // the floor corners: the ceiling's with the height flipped (scene.cpp:395-398)
+    }
+    struct Wall { TriangleMesh** mesh; ColorDbl color; };
+    const Wall walls[3] = { { &leftWall, ColorDbl(0.2, 0.01, 0.01) }, { &rightWall, ColorDbl(0.01, 0.2, 0.01) }, { &whiteSegments, ColorDbl(0.2) } };
+    for (const Wall& w : walls) {
+        *w.mesh = CreateObject<TriangleMesh>();
+        (*w.mesh)->material.color = w.color;
+    }
+    struct Quad { int wall, a, b, c, d; };
+    const Quad quads[5] = { { 0, 5, 1, 2, 6 }, { 1, 4, 7, 3, 0 }, { 2, 3, 2, 1, 0 } /* ceiling */, { 2, 7, 6, 2, 3 } /* back wall */, { 2, 4, 5, 6, 7 } /* floor */ };
+    for (const Quad& q : quads) (*walls[q.wall].mesh)->AddQuad(corner[q.a], corner[q.b], corner[q.c], corner[q.d]);
 }
 
 void CornellBoxScene::MoveCameraToRecommendedPosition(Camera& camera)
@@ -564,40 +565,43 @@ void CornellBoxScene::MoveCameraToRecommendedPosition(Camera& camera)
     camera.SetView(vec3(0.0f, 0.0f, halfLength), vec3(0.0f, 0.0f, 0.0f), vec3(0.0f, 1.0f, 0.0f));
 }
 
+// The example objects as two tables (source/scene.cpp:413-472): four spheres, then three boxes, in the reference's creation
+// order; every coordinate expression is the reference's own (mixed float / double arithmetic included), evaluated once.
 void CornellBoxScene::AddExampleObjects(float radius)
 {
-    SphereObject* lambertianSphere = CreateObject<SphereObject>();
-    SphereObject* specularSphere = CreateObject<SphereObject>();
-    SphereObject* orenNayarSphere = CreateObject<SphereObject>();
-    SphereObject* refractionSphere = CreateObject<SphereObject>();
-    for (SphereObject* s : { lambertianSphere, specularSphere, orenNayarSphere, refractionSphere }) {
-        s->radius = radius;
-        s->material.color = ColorDbl(0.5);
-    }
     const float widthOffset = halfWidth - radius;
     const float depthOffset = halfLength - radius;
-    lambertianSphere->position = vec3(-widthOffset, 0.0f, -depthOffset / 2.0);
-    specularSphere->position = vec3(0, 2.0, -halfLength + specularSphere->radius);
-    orenNayarSphere->position = vec3(widthOffset, 0.0f, -depthOffset / 2.0);
-    refractionSphere->position = vec3(0, -halfHeight + refractionSphere->radius + 1.5, -2);
-
-    Box* orenNayarBox = CreateObject<Box>();
-    orenNayarBox->SetGeometry({ halfWidth - 1.5f, -halfHeight, -depthOffset / 2.0 }, { 0.0f, 1.0f, 0.0f }, { -0.5f, 0.0f, 1.0f }, 2.0f, 2.0f, halfHeight - radius);
-    orenNayarBox->material.color = ColorDbl(0.01, 0.3, 0.8);
-    Box* lambertianBox = CreateObject<Box>();
-    lambertianBox->SetGeometry({ -halfWidth + 1.5f, -halfHeight, -depthOffset / 2.0 }, { 0.0f, 1.0f, 0.0f }, { 0.5f, 0.0f, 1.0f }, 2.0f, 2.0f, halfHeight - radius);
-    lambertianBox->material.color = ColorDbl(0.8, 0.4, 0.01);
-    Box* middleBox = CreateObject<Box>();
-    middleBox->SetGeometry({ 0, -halfHeight, -3 }, { 0.0f, 1.0f, 0.0f }, { 1.0f, 0.0f, 1.0f }, 4.0f, 4.0f, halfHeight - refractionSphere->radius - 2.3f);
-    middleBox->material.color = ColorDbl(0.5, 0.2, 0.8);
-
-    orenNayarBox->material.diffuse = DiffuseType::OrenNayar;
-    orenNayarSphere->material.diffuse = DiffuseType::OrenNayar;
-    orenNayarSphere->material.roughness = 0.5f;
-    orenNayarBox->material.roughness = 0.5f;
-    specularSphere->material.type = SurfaceType::Specular;
-    refractionSphere->material.type = SurfaceType::Refractive;
-    refractionSphere->material.refractiveIndex = 1.4f;
+    struct SphereSpec { vec3 position; SurfaceType type; DiffuseType diffuse; float roughness, ior; };
+    const Material plain;
+    const SphereSpec spheres[4] = {
+        { vec3(-widthOffset, 0.0f, -depthOffset / 2.0), SurfaceType::Diffuse, DiffuseType::Lambertian, plain.roughness, plain.refractiveIndex },
+        { vec3(0, 2.0, -halfLength + radius), SurfaceType::Specular, DiffuseType::Lambertian, plain.roughness, plain.refractiveIndex },
+        { vec3(widthOffset, 0.0f, -depthOffset / 2.0), SurfaceType::Diffuse, DiffuseType::OrenNayar, 0.5f, plain.refractiveIndex },
+        { vec3(0, -halfHeight + radius + 1.5, -2), SurfaceType::Refractive, DiffuseType::Lambertian, plain.roughness, 1.4f },
+    };
+    for (const SphereSpec& spec : spheres) {
+        SphereObject* s = CreateObject<SphereObject>();
+        s->radius = radius;
+        s->position = spec.position;
+        s->material.color = ColorDbl(0.5);
+        s->material.type = spec.type;
+        s->material.diffuse = spec.diffuse;
+        s->material.roughness = spec.roughness;
+        s->material.refractiveIndex = spec.ior;
+    }
+    struct BoxSpec { vec3 base, side; float width, depth, height; ColorDbl color; DiffuseType diffuse; float roughness; };
+    const BoxSpec boxes[3] = {
+        { { halfWidth - 1.5f, -halfHeight, -depthOffset / 2.0 }, { -0.5f, 0.0f, 1.0f }, 2.0f, 2.0f, halfHeight - radius, ColorDbl(0.01, 0.3, 0.8), DiffuseType::OrenNayar, 0.5f },
+        { { -halfWidth + 1.5f, -halfHeight, -depthOffset / 2.0 }, { 0.5f, 0.0f, 1.0f }, 2.0f, 2.0f, halfHeight - radius, ColorDbl(0.8, 0.4, 0.01), DiffuseType::Lambertian, plain.roughness },
+        { { 0, -halfHeight, -3 }, { 1.0f, 0.0f, 1.0f }, 4.0f, 4.0f, halfHeight - radius - 2.3f, ColorDbl(0.5, 0.2, 0.8), DiffuseType::Lambertian, plain.roughness },
+    };
+    for (const BoxSpec& spec : boxes) {
+        Box* box = CreateObject<Box>();
+        box->SetGeometry(spec.base, { 0.0f, 1.0f, 0.0f }, spec.side, spec.width, spec.depth, spec.height);
+        box->material.color = spec.color;
+        box->material.diffuse = spec.diffuse;
+        box->material.roughness = spec.roughness;
+    }
 }
 
 void CornellBoxScene::AddExampleLight(ColorDbl lightColor, bool usePoint)

@@ -393,3 +393,31 @@ def test_device_build_of_the_million_triangle_scene(backend, pkg, oracle, scene_
     want = oracle.trace_samples(sc, cam, px, sm, SEED, 100, portable_math=True, forward_sum=True)
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
     backend.upload_scene(scene_of("cornell"))
+
+
+def test_wavefront_pipeline_equals_the_render_kernel(backend, pkg, oracle, scene_of, monkeypatch):
+    """MCRT_WAVEFRONT=1 (k_wf_shade / k_wf_trace over path slots in HBM) on the 2000-triangle scene - glass
+    sphere included, so refractive splits park branches in the per-slot stacks: accumulators bit-identical to the oracle's,
+    ragged sample counts and image sizes, few slots (every slot works off many items) as well as more slots than items."""
+    flat = scene_of("config4_2k")
+    sc = oracle.scene(flat)
+    cam = oracle.camera(72, 40, 90.0, POS, TGT)
+    for slots in ("4096", "65536"):
+        monkeypatch.setenv("MCRT_WAVEFRONT", "1")
+        monkeypatch.setenv("MCRT_WF_SLOTS", slots)
+        wf = pkg.Backend(0)                                   # the knobs are read when the context is created
+        try:
+            wf.upload_scene(flat)
+            assert not wf.octree_info().lds_resident
+            wf.set_camera(cam)
+            wf.set_lanes_per_pixel(4)
+            wf.clear(); wf.render(3, 7, 100, SEED)
+            got = wf.read_accumulator()
+            want, _ = oracle.render(sc, cam, 3, 7, 100, SEED, threads=8, portable_math=True, forward_sum=True, lanes_per_pixel=4)
+            assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+            wf.render(10, 5, 100, SEED)                       # a second pass on top
+            want, _ = oracle.render(sc, cam, 10, 5, 100, SEED, threads=8, portable_math=True, forward_sum=True, lanes_per_pixel=4, sums=want)
+            assert np.array_equal(wf.read_accumulator(), want)
+        finally:
+            wf.close()
+    monkeypatch.delenv("MCRT_WAVEFRONT"); monkeypatch.delenv("MCRT_WF_SLOTS")

@@ -460,3 +460,29 @@ def test_million_triangle_scene(backend, pkg, scene_of, oracle):
     a = backend.read_accumulator()
     backend.clear(); backend.render(0, 16, 100, SEED)
     assert np.array_equal(a, backend.read_accumulator()) and np.isfinite(a).all() and a.mean() > 0
+
+
+def test_full_size_properties_config3(backend, pkg, scene_of, oracle):
+    """BASELINE config 3 at full size (Oren-Nayar + heavy refraction, 1024x1024x1024 = 1.07 G samples): sample count, the
+    path-tree statistics of SURVEY.md 3.2 (deep refractive paths: more rays and splits than the default scene), and random
+    pixels against the oracle's per-sample radiance summed in the pass's slice order, bit for bit."""
+    flat = _upload(backend, pkg, scene_of, "config3")
+    cam = oracle.camera(1024, 1024, 90.0, (0, 0, 5), (0, 0, 0))
+    backend.set_camera(cam)
+    backend.set_counting(True)
+    backend.clear(); backend.render(0, 64, 100, SEED)                 # the counting build on a 64-spp slice of the job
+    cnt = backend.counters()
+    backend.set_counting(False)
+    assert cnt["samples"] == 1024 * 1024 * 64
+    assert cnt["rays"] / cnt["samples"] > 5.0 and cnt["splits"] / cnt["samples"] > 0.2
+    backend.clear(); backend.render(0, 1024, 100, SEED)
+    a = backend.read_accumulator()
+    assert np.isfinite(a).all() and backend.dropped_samples() < 1024
+    lanes = backend.lanes_per_pixel(1024)
+    sc = oracle.scene(flat)
+    rng = np.random.default_rng(6)
+    for p in rng.integers(0, 1024 * 1024, 4).astype(np.uint32):
+        s = oracle.trace_samples(sc, cam, np.full(1024, p, np.uint32), np.arange(1024, dtype=np.uint32), SEED, 100, portable_math=True, forward_sum=True)
+        keep = s[np.isfinite(s).all(axis=1)]                           # non-finite samples are dropped (stated deviation)
+        if len(keep) == len(s):
+            assert np.array_equal(_sliced_sum(s, lanes), a.reshape(-1, 3)[p])
