@@ -333,6 +333,22 @@ MCRT_DEV bool tri_hit_rec(const TriRec& tr, V3 o, V3 d, float& t)
     t = f * dot(edge2, q);
     return t > kFltEpsilon;
 }
+// The same operations without the early returns: in the octree walk every lane of the wavefront sits through the whole test
+// anyway (some lane always gets to the end), and three nested branches cost more than the few instructions they skip.
+// Same values: every quantity is computed by the same operation from the same operands; a rejected triangle just computes a
+// t nobody reads (the reference writes it too, source/core/triangle.h:60).
+MCRT_DEV bool tri_hit_flat(const TriRec& tr, V3 o, V3 d, float& t)
+{
+    const V3 h = cross(d, tr.e2);
+    const float a = dot(tr.e1, h);
+    const float f = 1.0f / a;
+    const V3 s = o - tr.v0;
+    const float u = f * dot(s, h);
+    const V3 q = cross(s, tr.e1);
+    const float v = f * dot(d, q);
+    t = f * dot(tr.e2, q);
+    return !(fabsf(a) < kFltEpsilon) & !(u < 0.0f || u > 1.0f) & !(v < 0.0f || u + v > 1.0f) & (t > kFltEpsilon);
+}
 template <class P> MCRT_DEV bool tri_hit(P big, uint32_t rec, V3 o, V3 d, float& t)
 {
     return tri_hit_rec(load_tri(big, rec), o, d, t);
@@ -472,6 +488,7 @@ struct ScratchStack {
     MCRT_DEV uint32_t get(int i) const { return w_[i]; }
     MCRT_DEV bool room(int, int) const { return false; }
     MCRT_DEV void put_fast(int i, float t, uint32_t w) { put(i, t, w); }
+    MCRT_DEV void both(int i, float& t, uint32_t& w) const { t = t_[i]; w = w_[i]; }
 };
 // The first LDS_STACK_ENTRIES entries live in LDS (field-major, one dword column per thread of the 256-thread
 // block: bank = thread id, conflict-free whatever the lanes' stack depths), the rest in scratch memory.  Scratch
@@ -490,6 +507,11 @@ template <int kEntries> struct LdsStackT {
     }
     MCRT_DEV float t(int i) const { return i < kEntries ? __uint_as_float(col[(i * 2 + 0) * LDS_STACK_BLOCK]) : t_[i - kEntries]; }
     MCRT_DEV uint32_t get(int i) const { return i < kEntries ? col[(i * 2 + 1) * LDS_STACK_BLOCK] : w_[i - kEntries]; }
+    MCRT_DEV void both(int i, float& t, uint32_t& w) const
+    {
+        if (i < kEntries) { t = __uint_as_float(col[(i * 2 + 0) * LDS_STACK_BLOCK]); w = col[(i * 2 + 1) * LDS_STACK_BLOCK]; }
+        else { t = t_[i - kEntries]; w = w_[i - kEntries]; }
+    }
     // entries [i, i + n) all live in LDS: put_fast needs no check (one test per visit instead of one per push)
     MCRT_DEV bool room(int i, int n) const { return i + n <= kEntries; }
     MCRT_DEV void put_fast(int i, float t, uint32_t w) { col[(i * 2 + 0) * LDS_STACK_BLOCK] = __float_as_uint(t); col[(i * 2 + 1) * LDS_STACK_BLOCK] = w; }
@@ -562,12 +584,13 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
         } else {
             // next entry that was not entered behind the best hit so far
             float t_in;
+            uint32_t w_in;
             do {
                 if (sp == 0) return;
                 --sp;
-                t_in = st.t(sp);
+                st.both(sp, t_in, w_in);
             } while (t_in > best.t);
-            const uint32_t rec = st.get(sp) * NODE_STRIDE;
+            const uint32_t rec = w_in * NODE_STRIDE;
             const U4 ra = ld4(nodes, rec), rb = ld4(nodes, rec + 4), rc = ld4(nodes, rec + 8);
             // all three loads in one round trip: without this the compiler sinks the third into the `mask != 0` branch, behind the tight test
             asm volatile("" ::"v"(rc.x), "v"(rc.y), "v"(rc.z), "v"(rc.w));
@@ -603,18 +626,35 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
                     n_in[k] = tn - pp[k]; n_out[k] = tm + pp[k];
                     f_in[k] = tm - pp[k]; f_out[k] = tf + pp[k];
                 }
-                // octants in ray order: bit a of k clear = the half the ray meets first on axis a; far octants are pushed first
-                const bool fast = st.room(sp, 8);
+                // The eight octants in ray order (bit a of k clear = the half the ray meets first on axis a): first WHICH of them the
+                // ray passes, as one 8-bit mask without a branch - [0, best.t] is folded into the x intervals, an octant is three
+                // interval bounds: max3 / min3 / compare -, then one push per set bit, far octants first.  (Eight predicated
+                // push blocks cost the wavefront 8 x ~22 instructions and as many branches whatever the rays do; a ray passes
+                // two or three octants.)
+                n_in[0] = fmaxf(n_in[0], 0.0f); f_in[0] = fmaxf(f_in[0], 0.0f);
+                n_out[0] = fminf(n_out[0], best.t); f_out[0] = fminf(f_out[0], best.t);
+                // existing children, permuted into ray order: bit k of `have` = bit (k ^ flip) of mask
+                uint32_t have = mask;
+                if (flip & 1u) have = ((have & 0x55u) << 1) | ((have >> 1) & 0x55u);
+                if (flip & 2u) have = ((have & 0x33u) << 2) | ((have >> 2) & 0x33u);
+                if (flip & 4u) have = ((have & 0x0Fu) << 4) | ((have >> 4) & 0x0Fu);
+                uint32_t hitmask = 0;
 #pragma unroll
-                for (int k = 7; k >= 0; --k) {
-                    const float t0 = fmaxf(fmaxf((k & 1) ? f_in[0] : n_in[0], (k & 2) ? f_in[1] : n_in[1]), fmaxf((k & 4) ? f_in[2] : n_in[2], 0.0f));
-                    const float t1 = fminf(fminf((k & 1) ? f_out[0] : n_out[0], (k & 2) ? f_out[1] : n_out[1]), fminf((k & 4) ? f_out[2] : n_out[2], best.t));
-                    const uint32_t oct = (uint32_t)k ^ flip;
-                    if (((mask >> oct) & 1u) && t0 <= t1) {
-                        const uint32_t child = base + __popc(mask & ((1u << oct) - 1u));
-                        if (fast) st.put_fast(sp, t0, child); else st.put(sp, t0, child);
-                        ++sp;
-                    }
+                for (int k = 0; k < 8; ++k) {
+                    const float t0 = fmaxf(fmaxf((k & 1) ? f_in[0] : n_in[0], (k & 2) ? f_in[1] : n_in[1]), (k & 4) ? f_in[2] : n_in[2]);
+                    const float t1 = fminf(fminf((k & 1) ? f_out[0] : n_out[0], (k & 2) ? f_out[1] : n_out[1]), (k & 4) ? f_out[2] : n_out[2]);
+                    hitmask |= (t0 <= t1) ? (1u << k) : 0u;
+                }
+                hitmask &= have;
+                const bool fast = st.room(sp, 8);
+                while (hitmask) {
+                    const uint32_t k = 31u - (uint32_t)__clz((int)hitmask);      // the farthest octant left
+                    hitmask ^= 1u << k;
+                    const float t0 = fmaxf(fmaxf((k & 1u) ? f_in[0] : n_in[0], (k & 2u) ? f_in[1] : n_in[1]), (k & 4u) ? f_in[2] : n_in[2]);
+                    const uint32_t oct = k ^ flip;
+                    const uint32_t child = base + __popc(mask & ((1u << oct) - 1u));
+                    if (fast) st.put_fast(sp, t0, child); else st.put(sp, t0, child);
+                    ++sp;
                 }
             }
         }
@@ -647,7 +687,7 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
                     tr.v0 = mk(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
                     tr.e1 = mk(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
                     tr.e2 = mk(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x));
-                    h = tri_hit_rec(tr, o, d, t);
+                    h = tri_hit_flat(tr, o, d, t);
                 }
             }
             if (h && nearer(t, prim, best)) {
