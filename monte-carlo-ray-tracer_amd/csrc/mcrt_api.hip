@@ -1123,7 +1123,7 @@ size_t lds_for(const mcrt_ctx* c)
 size_t flat_lds_bytes(const mcrt_ctx* c) { return (size_t)c->view.ntri * TRI_STRIDE * 4u + 16u + (kBlock / 64) * FLAT_AREA_WORDS * 4u; }
 bool flat_ok(const mcrt_ctx* c)
 {
-    return c->view.has_pairs && c->view.ntri < (1u << FLAT_ELEM_BITS) && c->view.nobj <= 64u && flat_lds_bytes(c) <= 40u * 1024u;   // 4 blocks per CU
+    return c->view.has_pairs && c->view.ntri < (1u << FLAT_ELEM_BITS) && c->view.nobj < 4095u && flat_lds_bytes(c) <= 40u * 1024u;   // 4 blocks per CU
 }
 // what the kernels of the current accel mode get: the flat scan addresses triangles in its LDS copy
 SceneView view_for(const mcrt_ctx* c)

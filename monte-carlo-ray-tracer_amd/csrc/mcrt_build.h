@@ -63,7 +63,7 @@ __global__ void k_bld_boxes(Params P, const uint32_t* __restrict__ small_img, ui
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P.nprim) return;
-    // the object that owns primitive p (ids are assigned in (object, element) order; at most 64 objects)
+    // the object that owns primitive p (ids are assigned in (object, element) order; a few hundred objects at most)
     uint32_t obj = 0;
     for (uint32_t i = 0; i < P.nobj; ++i) if (small_img[off_obj + i * OBJ_STRIDE + OBJ_FIRST_PRIM] <= p) obj = i;
     const uint32_t* o = small_img + off_obj + obj * OBJ_STRIDE;

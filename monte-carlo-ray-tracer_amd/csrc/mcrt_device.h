@@ -673,15 +673,22 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
                 if (kCount) cn.spheres++;
                 h = sphere_hit(sm, orec, o, d, t);
             } else {
-                // mesh gate, evaluated once per (ray, mesh) on first contact
-                const uint64_t bit = 1ull << obj;
-                if (!(gate_known & bit)) {
+                // mesh gate, evaluated once per (ray, mesh) on first contact (objects beyond the 64 the cache holds: on every contact)
+                const uint64_t bit = obj < MAX_OBJECTS_GATED ? 1ull << obj : 0ull;
+                bool pass;
+                if (obj >= MAX_OBJECTS_GATED) {
                     if (kCount) cn.gates++;
-                    gate_known |= bit;
-                    if (gate_hit(sm, orec, o, d)) gate_pass |= bit;
+                    pass = gate_hit(sm, orec, o, d);
+                } else {
+                    if (!(gate_known & bit)) {
+                        if (kCount) cn.gates++;
+                        gate_known |= bit;
+                        if (gate_hit(sm, orec, o, d)) gate_pass |= bit;
+                    }
+                    pass = (gate_pass & bit) != 0ull;
                 }
                 h = false;
-                if (gate_pass & bit) {
+                if (pass) {
                     if (kCount) cn.tris++;
                     TriRec tr;
                     tr.v0 = mk(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));

@@ -262,7 +262,7 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
 {
     if (!sc || (sc->object_count && !sc->objects) || (sc->triangle_count && !sc->triangles)) { err = "null scene description"; return MCRT_ERR_INVALID; }
     if (sc->object_count == 0) { err = "scene has no objects"; return MCRT_ERR_INVALID; }
-    if (sc->object_count > MAX_OBJECTS_GATED) { err = "more than 64 objects: the per-ray mesh-gate cache is a 64-bit mask"; return MCRT_ERR_LIMIT; }
+    if (sc->object_count > MAX_OBJECTS) { err = "more than 512 objects: the object table has to fit in LDS"; return MCRT_ERR_LIMIT; }
     if (sc->triangle_count > 0x3FFFFFFFu) { err = "too many triangles"; return MCRT_ERR_LIMIT; }
 
     const uint32_t nobj = sc->object_count;

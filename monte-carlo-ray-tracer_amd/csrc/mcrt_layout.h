@@ -87,7 +87,8 @@ constexpr uint32_t MISS = 0xFFFFFFFFu;
 
 constexpr uint32_t MAX_TREE_DEPTH = 12;
 constexpr uint32_t TRAVERSAL_STACK = 7 * MAX_TREE_DEPTH + 4;
-constexpr uint32_t MAX_OBJECTS_GATED = 64;   // mesh-gate cache is a 64-bit mask per ray
+constexpr uint32_t MAX_OBJECTS_GATED = 64;   // the per-ray mesh-gate cache is a 64-bit mask: objects 0..63 are cached, later ones evaluated on every contact
+constexpr uint32_t MAX_OBJECTS = 512;        // object table (160 bytes each) has to fit the LDS budget next to the walk's stack
 
 struct SceneView {
     const uint32_t* small_img;   // global copies of the two images

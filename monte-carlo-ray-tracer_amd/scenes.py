@@ -181,3 +181,17 @@ def config4(cornell, n=1_000_000, seed=42):
     ltris = base.triangles[int(base.objects["first_triangle"][3]):]
     light["first_triangle"] = len(with_mesh.triangles)
     return abi.FlatScene(np.concatenate([with_mesh.objects, light]), np.concatenate([with_mesh.triangles, ltris]), base.background)
+
+
+def many_objects(cornell, meshes=120, tris_per_mesh=6, seed=7):
+    """The Cornell box plus `meshes` small triangle meshes of their own (clumps of the random soup, scaled up so that they
+    are hit): a scene with more objects than the 64 the per-ray mesh-gate cache holds."""
+    f = cornell
+    tri = random_mesh_triangles(meshes * tris_per_mesh, seed)
+    for m in range(meshes):
+        t = tri[m * tris_per_mesh:(m + 1) * tris_per_mesh]
+        centre = t["v0"][0].copy()
+        shift = (F(0.1) * np.arange(tris_per_mesh, dtype=F))[:, None] * np.array([1.0, 0.5, -0.7], F)
+        v = [(centre + (t[k] - t["v0"]) * F(8.0) + shift).astype(F) for k in ("v0", "v1", "v2")]
+        f = add_mesh(f, make_triangles(*v), tuple(float(x) for x in centre), material(color=0.3 + 0.005 * m))
+    return f

@@ -769,14 +769,21 @@ static hit_t octree_hit(const orc_scene* S, const orc_octree* T, const uint32_t*
                 int better;
                 if (O->kind == MCRT_OBJECT_SPHERE) { if (st) st->spheres++; h = sphere_hit(O, ro, rd, &t); }
                 else {
-                    uint64_t bit = 1ull << ob;
-                    if (!(gate_known & bit)) {
+                    int pass;
+                    if (ob >= 64u) {          /* beyond the 64-entry gate cache: evaluated on every contact */
                         if (st) st->gates++;
-                        gate_known |= bit;
-                        if (aabb_hit(O->aabb_min, O->aabb_max, ro, rd)) gate_pass |= bit;
+                        pass = aabb_hit(O->aabb_min, O->aabb_max, ro, rd);
+                    } else {
+                        uint64_t bit = 1ull << ob;
+                        if (!(gate_known & bit)) {
+                            if (st) st->gates++;
+                            gate_known |= bit;
+                            if (aabb_hit(O->aabb_min, O->aabb_max, ro, rd)) gate_pass |= bit;
+                        }
+                        pass = (gate_pass & bit) != 0;
                     }
                     h = 0;
-                    if (gate_pass & bit) { if (st) st->tris++; h = tri_hit(&S->tri[O->first_triangle + el], ro, rd, &t); }
+                    if (pass) { if (st) st->tris++; h = tri_hit(&S->tri[O->first_triangle + el], ro, rd, &t); }
                 }
                 better = h && (t < best.t || (t == best.t && bestPrim != 0xFFFFFFFFu && prim < bestPrim));
                 if (better) { best.obj = (int32_t)ob; best.elem = el; best.t = t; bestPrim = prim; }

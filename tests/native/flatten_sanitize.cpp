@@ -97,8 +97,8 @@ int main()
         bad += check("range outside", objs, tris, nullptr, MCRT_ERR_INVALID);
         objs = { mesh(0, 4) }; tris[1].v1[0] = NAN;
         bad += check("nan vertex", objs, tris, nullptr, MCRT_ERR_INVALID);
-        std::vector<mcrt_object> many(65, sphere(0, 0, 0, 1));
-        bad += check("65 objects", many, {}, nullptr, MCRT_ERR_LIMIT);
+        std::vector<mcrt_object> many(513, sphere(0, 0, 0, 1));
+        bad += check("513 objects", many, {}, nullptr, MCRT_ERR_LIMIT);
         bad += check("empty", {}, {}, nullptr, MCRT_ERR_INVALID);
     }
     std::printf(bad ? "FAILED\n" : "all ok\n");

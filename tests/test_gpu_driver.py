@@ -421,3 +421,32 @@ def test_wavefront_pipeline_equals_the_render_kernel(backend, pkg, oracle, scene
         finally:
             wf.close()
     monkeypatch.delenv("MCRT_WAVEFRONT"); monkeypatch.delenv("MCRT_WF_SLOTS")
+
+
+def test_scene_with_more_objects_than_the_gate_cache(backend, pkg, oracle, scene_of):
+    """131 objects: hits through the octree (host-built and device-built), the brute-force kernel and per-sample radiance equal the oracle's."""
+    from mcrt_amd import scenes
+
+    flat = scenes.many_objects(scene_of("cornell"))
+    sc = oracle.scene(flat)
+    rng = np.random.default_rng(17)
+    o = rng.uniform(-4.5, 4.5, (20000, 3)).astype(np.float32)
+    aim = flat.triangles["v0"][rng.integers(48, len(flat.triangles), 20000)] + rng.normal(scale=0.05, size=(20000, 3)).astype(np.float32)
+    d = (aim - o).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    want = oracle.intersect(sc, o, d)
+    for device_build in (False, True):
+        backend.upload_scene(flat, device_build=device_build)
+        for mode in (pkg.ACCEL_OCTREE, pkg.ACCEL_BRUTE, pkg.ACCEL_AUTO):
+            backend.set_accel(mode)
+            obj, elem, t = backend.intersect(o, d)
+            assert np.array_equal(obj, want[0]) and np.array_equal(elem, want[1]) and np.array_equal(t.view(np.uint32), want[2].view(np.uint32)), (device_build, mode)
+    cam = oracle.camera(48, 48, 90.0, POS, TGT)
+    backend.set_camera(cam)
+    px = rng.integers(0, 48 * 48, 300).astype(np.uint32)
+    sm = rng.integers(0, 500, 300).astype(np.uint32)
+    got = backend.trace_samples(px, sm, SEED, 100)
+    ref = oracle.trace_samples(sc, cam, px, sm, SEED, 100, portable_math=True, forward_sum=True)
+    same = (got.view(np.uint64) == ref.view(np.uint64)).all(axis=1) | (np.isnan(got).any(axis=1) & np.isnan(ref).any(axis=1))
+    assert same.all()
+    backend.upload_scene(scene_of("cornell"))
