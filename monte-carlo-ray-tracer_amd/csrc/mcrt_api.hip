@@ -785,7 +785,7 @@ __global__ __launch_bounds__(kBlock, kBlocksPerCu) void k_wf_trace(const WfArgs 
     const GlbPtr nodes = big + v.off_node, leaves = big + v.off_leaf;
     uint32_t slot = WF_NONE;
     bool exhausted = false;
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), inv = mk(0, 0, 0), padt = mk(0, 0, 0);
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), inv = mk(0, 0, 0), padt = mk(0, 0, 0), dts = mk(0, 0, 0);
     uint32_t flip = 0;
     // The wavefront owns a batch of queue entries [w_pos, w_end) (wave-uniform): lanes that need a ray take from it, the
     // batch is refilled with ONE atomic per kWfBatch entries - a per-fetch atomic on the one cursor serialised in L2
@@ -816,9 +816,7 @@ __global__ __launch_bounds__(kBlock, kBlocksPerCu) void k_wf_trace(const WfArgs 
                 const U4 c0 = a.state[slot], c1 = a.state[(size_t)a.slots + slot];
                 o = mk(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z));
                 d = mk(__uint_as_float(c1.x), __uint_as_float(c1.y), __uint_as_float(c1.z));
-                inv = mk(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
-                padt = mk(v.walk_pad * fabsf(inv.x), v.walk_pad * fabsf(inv.y), v.walk_pad * fabsf(inv.z));
-                flip = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+                OctreeWalk<LdsPtr, GlbPtr, kCount>::ray_setup(v, d, inv, padt, dts, flip);
                 walk.begin(sm, v, st, o, d, cn);
             }
             const uint32_t taken = (uint32_t)__popcll(need) < avail ? (uint32_t)__popcll(need) : avail;
@@ -826,7 +824,7 @@ __global__ __launch_bounds__(kBlock, kBlocksPerCu) void k_wf_trace(const WfArgs 
             need = __ballot(mine && !take);
         }
         if (__ballot(!walk.done()) == 0ull) break;     // nobody walks: every lane has stored its hit and found the queue empty
-        if (!walk.done()) walk.visit(sm, nodes, leaves, v, st, o, d, inv, padt, flip, 4u, cn);
+        if (!walk.done()) walk.visit(sm, nodes, leaves, v, st, o, d, inv, padt, dts, flip, 4u, cn);
     }
     if (kCount) flush_counters(a.r.counters, cn, rc);
 }

@@ -569,9 +569,9 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
     // A lane with a long list stays in leaf steps and does not pop meanwhile, so per ray the order of events is that of a
     // sequential walk; the wavefront, though, never sits through the longest list among its 64 nodes: a step costs one node
     // step plus one record whatever the lists look like (the chunked list loop it replaces ran at 13-17 of 64 lanes).
-    // inv: clamped reciprocals of the direction; padt = pad * |inv| per axis; flip: bit a set where the ray runs
+    // inv: clamped reciprocals of the direction; padt = pad * |inv| per axis; dts = root cell size * inv per axis; flip: bit a set where the ray runs
     // towards smaller coordinates on axis a (sign of inv, so that +-0 components are treated consistently).
-    template <class St> MCRT_DEV void visit(PS sm, PB nodes, PB leaves, const SceneView& v, St& st, V3 o, V3 d, V3 inv, V3 padt, uint32_t flip,
+    template <class St> MCRT_DEV void visit(PS sm, PB nodes, PB leaves, const SceneView& v, St& st, V3 o, V3 d, V3 inv, V3 padt, V3 dts, uint32_t flip,
                         uint32_t, Counters& cn)
     {
         U4 a, b, c;
@@ -614,15 +614,17 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
                 // per axis: entry / exit distances of the near half [near face - pad, mid + pad] and the far half [mid - pad, far face + pad]
                 float n_in[3], n_out[3], f_in[3], f_out[3];
                 const float cmn[3] = { __uint_as_float(rc.x), __uint_as_float(rc.y), __uint_as_float(rc.z) };
-                const float oo[3] = { o.x, o.y, o.z }, ii[3] = { inv.x, inv.y, inv.z }, pp[3] = { padt.x, padt.y, padt.z };
+                const float oo[3] = { o.x, o.y, o.z }, ii[3] = { inv.x, inv.y, inv.z }, pp[3] = { padt.x, padt.y, padt.z }, dd[3] = { dts.x, dts.y, dts.z };
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const float size = v.root_size[k] * scale;
-                    const float mid = cmn[k] + 0.5f * size, cmx = cmn[k] + size;
-                    const bool back = (flip >> k) & 1u;
-                    const float tn = ((back ? cmx : cmn[k]) - oo[k]) * ii[k];
-                    const float tm = (mid - oo[k]) * ii[k];
-                    const float tf = ((back ? cmn[k] : cmx) - oo[k]) * ii[k];
+                    // the three planes of an axis from ONE subtraction: the cell is the root cell scaled by 2^-depth, so the ray needs
+                    // dts * scale from face to face and half of that to the mid plane (against (plane - o) * inv that is a few ulps of t;
+                    // the padding is 256 ulps of the largest coordinate at least)
+                    const float t_lo = (cmn[k] - oo[k]) * ii[k];
+                    const float dt = dd[k] * scale;
+                    const float t_hi = t_lo + dt;
+                    const float tm = __fmaf_rn(dt, 0.5f, t_lo);
+                    const float tn = fminf(t_lo, t_hi), tf = fmaxf(t_lo, t_hi);
                     n_in[k] = tn - pp[k]; n_out[k] = tm + pp[k];
                     f_in[k] = tm - pp[k]; f_out[k] = tf + pp[k];
                 }
@@ -704,14 +706,23 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
         }
     }
 
+    // per-ray constants of the walk
+    static MCRT_DEV void ray_setup(const SceneView& v, V3 d, V3& inv, V3& padt, V3& dts, uint32_t& flip)
+    {
+        // Node and octant culling is conservative (boxes and cells are padded); reciprocals are clamped, see slab_rcp.
+        inv = mk(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
+        padt = mk(v.walk_pad * fabsf(inv.x), v.walk_pad * fabsf(inv.y), v.walk_pad * fabsf(inv.z));
+        dts = mk(v.root_size[0] * inv.x, v.root_size[1] * inv.y, v.root_size[2] * inv.z);
+        flip = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+    }
+
     // Advance every unfinished lane.  refill == 0: until all lanes of the wavefront are finished; otherwise
     // return once fewer than refill/64 of the lanes that came in unfinished are still walking.
     template <class St> MCRT_DEV void run(PS sm, PB big, const SceneView& v, St& st, V3 o, V3 d, Counters& cn, uint32_t refill, uint32_t chunk = 0xFFFFFFFFu)
     {
-        // Node and octant culling is conservative (boxes and cells are padded); reciprocals are clamped, see slab_rcp.
-        const V3 inv = mk(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
-        const V3 padt = mk(v.walk_pad * fabsf(inv.x), v.walk_pad * fabsf(inv.y), v.walk_pad * fabsf(inv.z));
-        const uint32_t flip = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+        V3 inv, padt, dts;
+        uint32_t flip;
+        ray_setup(v, d, inv, padt, dts, flip);
         const PB nodes = big + v.off_node;
         const PB leaves = big + v.off_leaf;
         const uint32_t entered = (uint32_t)__popcll(__ballot(!done()));
@@ -719,7 +730,7 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
         for (;;) {
             const uint32_t walking = (uint32_t)__popcll(__ballot(!done()));
             if (walking == 0 || walking < keep) break;
-            if (!done()) visit(sm, nodes, leaves, v, st, o, d, inv, padt, flip, chunk, cn);
+            if (!done()) visit(sm, nodes, leaves, v, st, o, d, inv, padt, dts, flip, chunk, cn);
         }
     }
 };

@@ -3,7 +3,7 @@
 //   main.cpp:234-242   build the default scene, camera, PrepareForRayTracing
 //   main.cpp:100-184   render loop            -> Scene::Render (GPU), progressive passes
 //   main.cpp:142-164   tonemap + 8-bit store  -> Scene::Resolve (GPU)
-//   screenshot.cpp     PNG of the framebuffer -> binary PPM (P6) of the BGRA8 buffer
+//   screenshot.cpp     PNG of the framebuffer -> --screenshot NAME (TakeScreenshot: NAME00001.png, ...), --out FILE.png|.ppm
 //   main.cpp:59-62,250-262   one worker thread per hardware thread -> --devices: one thread + context per GPU
 //   main.cpp:70-86     RAY_TRACE_RANDOM pixel picks -> --random-pixels
 //
@@ -11,7 +11,7 @@
 //                    [--depth D] [--seed S] [--tonemap reinhard|exposure|none] [--gamma G]
 //                    [--exposure E] [--point-light] [--obj FILE x y z] [--unlit] [--device I]
 //                    [--devices I,J,...] [--random-pixels N [--pick-seed S]] [--device-build]
-//                    [--out image.ppm] [--raw accum.f64] [--checkpoint FILE] [--resume FILE]
+//                    [--out image.ppm|image.png] [--screenshot NAME] [--raw accum.f64] [--checkpoint FILE] [--resume FILE]
 //
 // --devices I,J,...  one context and one host thread per listed GPU.  Every pass of P samples per pixel is split
 // into contiguous ranges of global sample indices, one per device (the first P % n devices take one sample more);
@@ -115,7 +115,7 @@ bool WritePPM(const std::string& path, const std::vector<uint8_t>& bgra, int w, 
 
 int main(int argc, char** argv)
 {
-    std::string sceneName = "cornell", out = "render.ppm", raw, tonemapName = "reinhard", objPath, checkpoint, resume;
+    std::string sceneName = "cornell", out = "render.ppm", screenshot, raw, tonemapName = "reinhard", objPath, checkpoint, resume;
     unsigned width = 640, height = 480, spp = 64, pass = 64, depth = 100;   // main.cpp:33-41 defaults
     uint64_t seed = 0x5EED0001ull, pickSeed = 1, randomPixels = 0;
     double gamma = 2.2, exposure = 1.0;                                     // main.cpp:47-48
@@ -151,6 +151,7 @@ int main(int argc, char** argv)
             }
         }
         else if (a == "--out") out = next("--out");
+        else if (a == "--screenshot") screenshot = next("--screenshot");
         else if (a == "--raw") raw = next("--raw");
         else if (a == "--checkpoint") checkpoint = next("--checkpoint");
         else if (a == "--resume") resume = next("--resume");
@@ -318,7 +319,9 @@ int main(int argc, char** argv)
     uint64_t droppedTotal = 0;
     for (auto& sc : scenes) { uint64_t d = 0; if (mcrt_dropped_samples(sc->Context(), &d) == MCRT_OK) droppedTotal += d; }
     if (droppedTotal) std::printf("%llu non-finite samples dropped\r\n", (unsigned long long)droppedTotal);
-    if (!WritePPM(out, image, int(width), int(height))) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
+    const bool png = out.size() >= 4 && out.compare(out.size() - 4, 4, ".png") == 0;
+    if (!(png ? WritePNG(out, image, width, height) : WritePPM(out, image, int(width), int(height)))) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
+    if (!screenshot.empty() && TakeScreenshot(screenshot, image, width, height).empty()) return 1;
     if (!raw.empty() && !unlit) {
         if (!randomPixels && !scene->ReadBack(camera)) return 1;
         FILE* f = std::fopen(raw.c_str(), "wb");

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <iostream>
 #include <random>
 #include <sstream>
 
@@ -609,6 +610,93 @@ void CornellBoxScene::AddExampleLight(ColorDbl lightColor, bool usePoint)
     AddLightAt(*this, vec3{ 0.0f, halfHeight - 0.001f, 0.0f }, vec2{ halfWidth / 3.0f, halfHeight / 3.0f }, lightColor, usePoint);
 }
 
+// ------------------------------------------------------------------- screenshot (source/opengl/screenshot.cpp)
+namespace {
+uint32_t Crc32(uint32_t crc, const uint8_t* p, size_t n)
+{
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        ready = true;
+    }
+    crc = ~crc;
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+    return ~crc;
+}
+void PutBE32(std::vector<uint8_t>& out, uint32_t v) { for (int s = 24; s >= 0; s -= 8) out.push_back(uint8_t(v >> s)); }
+void PutChunk(std::vector<uint8_t>& out, const char type[4], const std::vector<uint8_t>& data)
+{
+    PutBE32(out, uint32_t(data.size()));
+    const size_t at = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), data.begin(), data.end());
+    PutBE32(out, Crc32(0u, out.data() + at, out.size() - at));
+}
+} // namespace
+
+bool WritePNG(const std::string& path, const std::vector<uint8_t>& bgra8, unsigned width, unsigned height)
+{
+    if (width == 0 || height == 0 || bgra8.size() < size_t(width) * height * 4) return false;
+    // scanlines: filter byte 0 + RGBA
+    std::vector<uint8_t> raw;
+    raw.reserve((size_t(width) * 4 + 1) * height);
+    for (unsigned y = 0; y < height; ++y) {
+        raw.push_back(0);
+        for (unsigned x = 0; x < width; ++x) {
+            const uint8_t* p = &bgra8[(size_t(y) * width + x) * 4];
+            raw.push_back(p[2]); raw.push_back(p[1]); raw.push_back(p[0]); raw.push_back(p[3]);
+        }
+    }
+    // zlib stream of stored blocks (at most 65535 bytes each) + Adler-32
+    std::vector<uint8_t> z = { 0x78, 0x01 };
+    uint32_t a = 1, b = 0;
+    for (size_t at = 0; at < raw.size();) {
+        const size_t n = std::min<size_t>(65535, raw.size() - at);
+        z.push_back(at + n == raw.size() ? 1 : 0);
+        z.push_back(uint8_t(n)); z.push_back(uint8_t(n >> 8)); z.push_back(uint8_t(~n)); z.push_back(uint8_t(~n >> 8));
+        z.insert(z.end(), raw.begin() + at, raw.begin() + at + n);
+        for (size_t i = at; i < at + n; ++i) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+        at += n;
+    }
+    PutBE32(z, (b << 16) | a);
+    std::vector<uint8_t> out = { 0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n' };
+    std::vector<uint8_t> ihdr;
+    PutBE32(ihdr, width); PutBE32(ihdr, height);
+    const uint8_t tail[5] = { 8, 6, 0, 0, 0 };       // 8 bits per channel, RGBA, deflate, adaptive filtering, no interlace
+    ihdr.insert(ihdr.end(), tail, tail + 5);
+    PutChunk(out, "IHDR", ihdr);
+    PutChunk(out, "IDAT", z);
+    PutChunk(out, "IEND", {});
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+    return (std::fclose(f) == 0) && ok;
+}
+
+std::string TakeScreenshot(std::string filename, const std::vector<uint8_t>& bgra8, unsigned screenWidth, unsigned screenHeight)
+{
+    const size_t lastdot = filename.find_last_of(".");
+    if (lastdot != std::string::npos) filename = filename.substr(0, lastdot);      // screenshot.cpp:18-24
+    const std::string baseName = filename;
+    int count = 0;
+    do {                                                                           // screenshot.cpp:31-37
+        count++;
+        const std::string digits = std::to_string(count);
+        filename = baseName + std::string(digits.length() < 5 ? 5 - digits.length() : 0, '0') + digits + ".png";
+    } while (std::ifstream(filename).good());
+    if (!WritePNG(filename, bgra8, screenWidth, screenHeight)) {
+        std::cout << "encoder error: cannot write " << filename << std::endl;
+        return std::string();
+    }
+    std::cout << "Screenshot saved to " + filename + "\r\n";
+    return filename;
+}
+
 // ------------------------------------------------------------------- C shim
 // Lets tests (ctypes) build the example scenes through this layer and compare the flat description
 // with dumps of the reference's own objects.
@@ -674,6 +762,15 @@ void mcrt_host_accumulate(unsigned width, unsigned height, uint64_t n, const uin
             o[0] = c.r; o[1] = c.g; o[2] = c.b;
             out_counts[size_t(y) * width + x] = pb.GetRayCount(x, y);
         }
+}
+
+// TakeScreenshot (test hook): the name written is copied to out_name (empty string on failure)
+int mcrt_host_take_screenshot(const char* filename, const uint8_t* bgra8, unsigned width, unsigned height, char* out_name, unsigned out_cap)
+{
+    const std::vector<uint8_t> image(bgra8, bgra8 + size_t(width) * height * 4);
+    const std::string name = TakeScreenshot(filename, image, width, height);
+    if (out_name && out_cap) { std::strncpy(out_name, name.c_str(), out_cap - 1); out_name[out_cap - 1] = 0; }
+    return name.empty() ? 1 : 0;
 }
 
 int mcrt_host_scene_flatten(void* scene, mcrt_scene_desc* out) { return static_cast<Scene*>(scene)->Flatten(*out) ? 0 : 1; }

@@ -264,6 +264,13 @@ public:
     virtual void MoveCameraToRecommendedPosition(Camera& camera);
 };
 
+// source/opengl/screenshot.cpp:13-76 without the window: the image is the resolved BGRA8 buffer (Scene::Resolve, top row first)
+// instead of the GL framebuffer.  TakeScreenshot keeps the reference's file naming - extension stripped, a five-digit counter
+// appended, the first name that does not exist yet ("shot00001.png", "shot00002.png", ...) - and returns the name written
+// (empty on failure).  WritePNG: 8-bit RGBA, one IDAT of stored (uncompressed) deflate blocks: any PNG reader opens it.
+bool WritePNG(const std::string& path, const std::vector<uint8_t>& bgra8, unsigned width, unsigned height);
+std::string TakeScreenshot(std::string filename, const std::vector<uint8_t>& bgra8, unsigned screenWidth, unsigned screenHeight);
+
 class HexagonScene : public Scene {
 protected:
     TriangleMesh *ceiling, *floor, *walls1, *walls2, *walls3;

@@ -148,7 +148,7 @@ def test_driver_raw_output_equals_the_oracle(oracle, pkg, scene_of, tmp_path):
     """mcrt_render (CornellBoxScene of the host mirror -> Scene::Render in passes -> --raw) against oracle.render on the
     reference's dumped scene: bit-exact, pass by pass in the same slice order."""
     raw = tmp_path / "o.f64"
-    _run(["--width", 96, "--height", 72, "--spp", 12, "--pass", 5, "--out", tmp_path / "o.ppm", "--raw", raw])
+    _run(["--width", 96, "--height", 72, "--spp", 12, "--pass", 5, "--out", tmp_path / "o.ppm", "--raw", raw, "--screenshot", tmp_path / "shot.png"])
     flat = scene_of("cornell")
     cam = oracle.camera(96, 72, 90.0, POS, TGT)
     sc = oracle.scene(flat)
@@ -161,6 +161,10 @@ def test_driver_raw_output_equals_the_oracle(oracle, pkg, scene_of, tmp_path):
     head = b"P6\n96 72\n255\n"
     bgra, _ = oracle.resolve(want, 12, pkg.TONEMAP_REINHARD, portable_math=True)
     assert np.array_equal(np.frombuffer(data[len(head):], np.uint8).reshape(-1, 3), bgra[:, 2::-1])
+    # --screenshot: TakeScreenshot's numbered PNG (screenshot.cpp:31-37) of the same buffer
+    from test_host_and_abi import _read_png
+    w, h, rgba = _read_png(tmp_path / "shot00001.png")
+    assert (w, h) == (96, 72) and np.array_equal(rgba.reshape(-1, 4), bgra[:, [2, 1, 0, 3]])
 
 
 def test_driver_devices_list_splits_the_samples(oracle, pkg, scene_of, tmp_path):

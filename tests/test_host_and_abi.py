@@ -376,3 +376,46 @@ def test_flatten_under_sanitizers(tmp_path):
                     os.path.join(csrc, "mcrt_flatten.cpp"), "-o", exe], check=True, timeout=300)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "all ok" in r.stdout, r.stdout + r.stderr
+
+
+def _read_png(path):
+    """Minimal PNG reader for 8-bit RGBA without interlace (checks every chunk CRC): returns (width, height, rows of RGBA bytes)."""
+    import struct
+    import zlib
+
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    at, chunks = 8, []
+    while at < len(raw):
+        n, kind = struct.unpack(">I4s", raw[at:at + 8])
+        data = raw[at + 8:at + 8 + n]
+        assert struct.unpack(">I", raw[at + 8 + n:at + 12 + n])[0] == zlib.crc32(kind + data)
+        chunks.append((kind, data))
+        at += 12 + n
+    assert [k for k, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    w, h, depth, colour, comp, filt, lace = struct.unpack(">IIBBBBB", chunks[0][1])
+    assert (depth, colour, comp, filt, lace) == (8, 6, 0, 0, 0)
+    lines = zlib.decompress(chunks[1][1])            # checks the Adler-32 too
+    assert len(lines) == h * (1 + 4 * w)
+    rows = np.frombuffer(lines, np.uint8).reshape(h, 1 + 4 * w)
+    assert (rows[:, 0] == 0).all()
+    return w, h, rows[:, 1:].reshape(h, w, 4)
+
+
+def test_host_take_screenshot(host, tmp_path):
+    """TakeScreenshot (screenshot.cpp:13-76): extension stripped, five-digit counter, first free name; the PNG holds the
+    BGRA8 buffer as RGBA, top row first.  An image of more than 65535 bytes exercises the split into stored blocks."""
+    host.mcrt_host_take_screenshot.argtypes = [C.c_char_p, C.c_void_p, C.c_uint, C.c_uint, C.c_char_p, C.c_uint]
+    rng = np.random.default_rng(3)
+    w, h = 201, 97
+    bgra = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    name = C.create_string_buffer(512)
+    base = str(tmp_path / "shot.bmp").encode()
+    for k in (1, 2, 3):
+        assert host.mcrt_host_take_screenshot(base, bgra.ctypes.data, w, h, name, 512) == 0
+        assert name.value.decode() == str(tmp_path / ("shot%05d.png" % k))
+    gw, gh, rgba = _read_png(name.value.decode())
+    assert (gw, gh) == (w, h)
+    assert np.array_equal(rgba, bgra[:, :, [2, 1, 0, 3]])
+    assert host.mcrt_host_take_screenshot(str(tmp_path / "no_such_dir" / "x").encode(), bgra.ctypes.data, w, h, name, 512) == 1
+    assert name.value == b""
