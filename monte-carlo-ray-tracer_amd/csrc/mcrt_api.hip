@@ -466,7 +466,15 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
             const uint64_t want = __ballot(ln.state == ST_FETCH);
             fetch_ok = (uint32_t)__popcll(want) >= kFetchMin || want == busy;
         }
+#ifdef MCRT_SECTION_PROFILE
+        const unsigned long long pt_pre = PROF_NOW();
+        PROF_ADD(PF_ITER, 1); PROF_ADD(PF_PRE_LANES, __popcll(__ballot(ln.state == ST_NEW || (ln.state == ST_FETCH && fetch_ok))));
+#endif
         ln.pre(fetch_ok, work, cam, seed, max_depth, exs, ex, rc, kCount);
+#ifdef MCRT_SECTION_PROFILE
+        const unsigned long long pt_cast = PROF_NOW();
+        PROF_ADD(PF_PRE_T, pt_cast - pt_pre);
+#endif
 
         Hit hit;
         {
@@ -492,10 +500,30 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
                 hit = walk.best;
             } else {
                 hit = cast<kAccel, PS, PB, kCount>(sm, big, v, ln.ro, ln.rd, cn, live);
+#ifdef MCRT_SECTION_PROFILE
+                PROF_ADD(PF_CAST_T, PROF_NOW() - pt_cast); PROF_ADD(PF_CAST_LANES, __popcll(__ballot(live)));
+#endif
                 if (!live) continue;
             }
         }
+#ifdef MCRT_SECTION_PROFILE
+        const unsigned long long pt_post = PROF_NOW();
+        const uint32_t state_before = ln.state;
+        const uint64_t in_post = __ballot(1);
+#endif
         ln.post(hit, sm, big, v, background, pend, keep_nonfinite, work, ex, rc, kCount);
+#ifdef MCRT_SECTION_PROFILE
+        {
+            // the `continue` above leaves only the live lanes here: lane 0 may be missing, the first lane present adds for the wavefront
+            const uint64_t heavy = __ballot(state_before == ST_TRACE && ln.state == ST_SHADOW);
+            const uint64_t n_t = __popcll(__ballot(state_before == ST_TRACE)), n_s = __popcll(__ballot(state_before == ST_SHADOW));
+            if ((threadIdx.x & 63u) == (uint32_t)__ffsll((unsigned long long)in_post) - 1u) {
+                unsigned long long* p = prof_slots();
+                p[PF_POST_T] += PROF_NOW() - pt_post; p[PF_POST_TRACE_LANES] += n_t; p[PF_POST_SHADOW_LANES] += n_s;
+                p[PF_POST_HEAVY] += heavy ? 1u : 0u; p[PF_POST_HEAVY_LANES] += (unsigned long long)__popcll(heavy);
+            }
+        }
+#endif
     }
 }
 
@@ -605,7 +633,15 @@ __global__ __launch_bounds__(kBlock, 4) void k_render(const RenderArgs a)
     Counters cn = { 0, 0, 0, 0, 0 };
     RenderCounters rc = { 0, 0, 0 };
     RenderWork work = { a, 0u, 0u };
+#ifdef MCRT_SECTION_PROFILE
+    if ((threadIdx.x & 63u) < 32u) prof_slots()[threadIdx.x & 63u] = 0ull;
+    const unsigned long long pt_kernel = PROF_NOW();
+#endif
     trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount, kMulti>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, false, cn, rc, work, a.policy, walk_lds);
+#ifdef MCRT_SECTION_PROFILE
+    PROF_ADD(PF_WAVES, 1); PROF_ADD(PF_TOTAL_T, PROF_NOW() - pt_kernel);
+    if ((threadIdx.x & 63u) < (uint32_t)PF_COUNT) atomicAdd(&g_prof[threadIdx.x & 63u], prof_slots()[threadIdx.x & 63u]);
+#endif
     if (work.dropped_total) atomicAdd(a.dropped, (unsigned long long)work.dropped_total);
     if (kCount) flush_counters(a.counters, cn, rc);
 }
@@ -1425,6 +1461,16 @@ template <class T> struct DevBuf {
 
 // ======================================================================== ABI
 extern "C" {
+
+#ifdef MCRT_SECTION_PROFILE
+// diagnostic builds only: read and clear the section profile (tools/section_profile.py)
+int mcrt_debug_section_profile(uint64_t out[32])
+{
+    static const unsigned long long zero[32] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(zero)) != hipSuccess) return MCRT_ERR_HIP;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, sizeof(zero)) == hipSuccess ? MCRT_OK : MCRT_ERR_HIP;
+}
+#endif
 
 int mcrt_create(int device_id, mcrt_ctx** out_ctx)
 {

@@ -402,6 +402,24 @@ template <class P> MCRT_DEV bool gate_hit(P sm, uint32_t orec, V3 o, V3 d)
     return tmax >= tmin;
 }
 
+// Section profile (diagnostic builds only, -DMCRT_SECTION_PROFILE; tools/section_profile.py): per wavefront, the reference-clock
+// time and the number of lanes with real work in each part of the loop.  Lane 0 of a wavefront keeps the sums in LDS (all the
+// places that add are wave-uniform code) and adds them to g_prof when the kernel ends.
+#ifdef MCRT_SECTION_PROFILE
+enum : int { PF_ITER = 0, PF_PRE_T, PF_PRE_LANES, PF_CAST_T, PF_CAST_LANES, PF_SCAN_T, PF_SCAN_STEPS, PF_SCAN_LANES, PF_DEAL_T, PF_DEAL_STEPS, PF_DEAL_LANES,
+              PF_POST_T, PF_POST_TRACE_LANES, PF_POST_SHADOW_LANES, PF_POST_HEAVY, PF_POST_HEAVY_LANES, PF_WAVES, PF_TOTAL_T, PF_COUNT };
+__device__ unsigned long long g_prof[32];
+MCRT_DEV unsigned long long* prof_slots()
+{
+    static __shared__ unsigned long long s[4 * 32];
+    return s + (threadIdx.x >> 6) * 32;
+}
+#define PROF_NOW() __builtin_readcyclecounter()
+#define PROF_ADD(slot_, value_) do { const unsigned long long pv_ = (unsigned long long)(value_); if ((threadIdx.x & 63u) == 0u) prof_slots()[slot_] += pv_; } while (0)
+#else
+#define PROF_ADD(slot_, value_) ((void)0)
+#endif
+
 struct Counters { uint32_t rays, nodes, tris, spheres, gates; };
 
 struct Hit { uint32_t prim; uint32_t obj; uint32_t elem; float t; };   // obj == MISS on a miss
@@ -984,6 +1002,10 @@ MCRT_DEV Hit cast_flat(CstPtr sm, LdsPtr big, LdsRw area, const SceneView& v, V3
             // Most of the wavefront needs this mesh (the walls of a closed room): the lock-step pair loop of
             // cast_scan costs 38 instructions per lane and triangle against ~100 for a dealt pair, so it wins
             // from about 24 passing lanes up.
+#ifdef MCRT_SECTION_PROFILE
+            const unsigned long long pt0 = PROF_NOW();
+            PROF_ADD(PF_SCAN_STEPS, (count + 1u) / 2u); PROF_ADD(PF_SCAN_LANES, (unsigned long long)__popcll(mask) * ((count + 1u) / 2u));
+#endif
             if (pass) {
                 CstPtr pr = (CstPtr)v.big_img + v.off_pair + (size_t)rec[OBJ_FIRST_PAIR] * PAIR_STRIDE;
                 for (uint32_t k = 0; k < count; k += 2, pr += PAIR_STRIDE) {
@@ -1003,8 +1025,14 @@ MCRT_DEV Hit cast_flat(CstPtr sm, LdsPtr big, LdsRw area, const SceneView& v, V3
                     pair_exact(a, x, y, z, i, k, best);
                 }
             }
+#ifdef MCRT_SECTION_PROFILE
+            PROF_ADD(PF_SCAN_T, PROF_NOW() - pt0);
+#endif
             continue;
         }
+#ifdef MCRT_SECTION_PROFILE
+        const unsigned long long pt1 = PROF_NOW();
+#endif
         if (pass) list[(uint32_t)__popcll(mask & below)] = lane;       // compact the passing rays
         wave_sync();
         const uint32_t total = (uint32_t)__popcll(mask) * count;
@@ -1037,6 +1065,9 @@ MCRT_DEV Hit cast_flat(CstPtr sm, LdsPtr big, LdsRw area, const SceneView& v, V3
             }
         }
         wave_sync();                                                  // the list is reused by the next mesh
+#ifdef MCRT_SECTION_PROFILE
+        PROF_ADD(PF_DEAL_T, PROF_NOW() - pt1); PROF_ADD(PF_DEAL_STEPS, (total + nact - 1u) / nact); PROF_ADD(PF_DEAL_LANES, total);
+#endif
     }
     const unsigned long long key = *(__attribute__((address_space(3))) unsigned long long*)(keys + lane * 2u);
     const float tm = __uint_as_float((uint32_t)(key >> 32));
