@@ -502,6 +502,8 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
                 hit = cast<kAccel, PS, PB, kCount>(sm, big, v, ln.ro, ln.rd, cn, live);
 #ifdef MCRT_SECTION_PROFILE
                 PROF_ADD(PF_CAST_T, PROF_NOW() - pt_cast); PROF_ADD(PF_CAST_LANES, __popcll(__ballot(live)));
+                PROF_ADD(PF_IDLE_FETCH, __popcll(__ballot(ln.state == ST_FETCH))); PROF_ADD(PF_IDLE_DONE, __popcll(__ballot(ln.state == ST_DONE)));
+                PROF_ADD(PF_IDLE_BATCH, __popcll(__ballot(!live && ln.state != ST_FETCH && ln.state != ST_DONE)));
 #endif
                 if (!live) continue;
             }

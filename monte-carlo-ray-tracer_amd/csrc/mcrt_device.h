@@ -407,7 +407,8 @@ template <class P> MCRT_DEV bool gate_hit(P sm, uint32_t orec, V3 o, V3 d)
 // places that add are wave-uniform code) and adds them to g_prof when the kernel ends.
 #ifdef MCRT_SECTION_PROFILE
 enum : int { PF_ITER = 0, PF_PRE_T, PF_PRE_LANES, PF_CAST_T, PF_CAST_LANES, PF_SCAN_T, PF_SCAN_STEPS, PF_SCAN_LANES, PF_DEAL_T, PF_DEAL_STEPS, PF_DEAL_LANES,
-              PF_POST_T, PF_POST_TRACE_LANES, PF_POST_SHADOW_LANES, PF_POST_HEAVY, PF_POST_HEAVY_LANES, PF_WAVES, PF_TOTAL_T, PF_COUNT };
+              PF_POST_T, PF_POST_TRACE_LANES, PF_POST_SHADOW_LANES, PF_POST_HEAVY, PF_POST_HEAVY_LANES, PF_WAVES, PF_TOTAL_T, PF_IDLE_FETCH, PF_IDLE_DONE, PF_IDLE_BATCH,
+              PF_COUNT };
 __device__ unsigned long long g_prof[32];
 MCRT_DEV unsigned long long* prof_slots()
 {

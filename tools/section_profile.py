@@ -13,7 +13,7 @@ import mcrt_pkg
 
 pkg = mcrt_pkg.load()
 NAMES = ["iter", "pre_t", "pre_lanes", "cast_t", "cast_lanes", "scan_t", "scan_steps", "scan_lanes", "deal_t", "deal_steps", "deal_lanes", "post_t",
-         "post_trace_lanes", "post_shadow_lanes", "post_heavy", "post_heavy_lanes", "waves", "total_t"]
+         "post_trace_lanes", "post_shadow_lanes", "post_heavy", "post_heavy_lanes", "waves", "total_t", "idle_fetch", "idle_done", "idle_batch"]
 scene = sys.argv[1] if len(sys.argv) > 1 else "config2"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 W = H = 1024
@@ -46,3 +46,5 @@ print(f"  {'loop control, waiting lanes, tail':36s} {100.0 * (tot - acc) / tot:5
 print(f"  post: {p['post_trace_lanes'] / it:.1f} lanes after a camera/bounce ray, {p['post_shadow_lanes'] / it:.1f} after a shadow ray per iteration; a diffuse hit is shaded in "
       f"{100.0 * p['post_heavy'] / it:.0f} % of the iterations, by {p['post_heavy_lanes'] / max(p['post_heavy'], 1):.1f} lanes")
 print(f"  scan steps per iteration {p['scan_steps'] / it:.2f}, deal steps per iteration {p['deal_steps'] / it:.2f}")
+print(f"  lanes without a ray per iteration: {p['idle_fetch'] / it:.1f} waiting to fetch with the others of their round, {p['idle_batch'] / it:.1f} trace lanes waiting for their batch, "
+      f"{p['idle_done'] / it:.1f} out of work (end of the launch)")
