@@ -156,7 +156,9 @@ int mcrt_set_stream(mcrt_ctx* ctx, void* hip_stream);
 /* Flatten + upload the scene: Scene::PrepareForRayTracing,
  * source/scene.cpp:38-59 (light cache :41-49; the octree of
  * source/accelerationstructures/octree.h:77-92 is rebuilt here as a flat,
- * per-primitive structure of node and leaf records).  `accel` may be NULL. */
+ * per-primitive structure of node and leaf records).  `accel` may be NULL.
+ * Limits (MCRT_ERR_LIMIT): at most 512 objects, and their table has to fit the
+ * LDS budget; octree depth <= 256, fewer than 2^24 nodes. */
 int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* scene,
                       const mcrt_accel_params* accel);
 
