@@ -310,6 +310,30 @@ def test_empty_and_ragged_inputs(backend, pkg, scene_of, oracle):
     assert np.array_equal(d0, want0)
 
 
+@pytest.mark.parametrize("size", [(1, 1), (1, 130), (257, 1), (9, 7)])
+def test_degenerate_image_sizes(backend, pkg, scene_of, oracle, size):
+    """One-pixel, one-column and one-row images (tiles mostly outside the image, more sample slices than some passes have samples);
+    a pass of zero samples leaves the sums as they are."""
+    _upload(backend, pkg, scene_of, "cornell")
+    w, h = size
+    cam = oracle.camera(w, h, 90.0, (0, 0, 5), (0, 0, 0))
+    backend.set_camera(cam)
+    sc = oracle.scene(scene_of("cornell"))
+    backend.clear()
+    want = None
+    done = 0
+    for n in (1, 40, 0, 7):
+        backend.render(done, n, 100, SEED)
+        if n:
+            want, _ = oracle.render(sc, cam, done, n, 100, SEED, threads=4, portable_math=True, forward_sum=True, sums=want,
+                                     lanes_per_pixel=pkg.lanes_per_pixel(w, h, n))
+        done += n
+        assert np.array_equal(backend.read_accumulator(), want)
+    bgra, mean = backend.resolve(pkg.TONEMAP_REINHARD, done)
+    ref_bgra, ref_mean = oracle.resolve(want, done, pkg.TONEMAP_REINHARD, portable_math=True)
+    assert np.array_equal(bgra.reshape(-1, 4), ref_bgra.reshape(-1, 4)) and np.array_equal(mean.reshape(-1, 3), np.asarray(ref_mean).reshape(-1, 3))
+
+
 def test_trace_rays_explicit_generator(backend, pkg, oracle, scene_of, golden):
     """Scene::TraceRay(ray, generator, depth, importance): explicit rays, caller-owned generator state that
     comes back advanced, non-unit importance."""
