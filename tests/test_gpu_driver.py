@@ -454,3 +454,44 @@ def test_scene_with_more_objects_than_the_gate_cache(backend, pkg, oracle, scene
     same = (got.view(np.uint64) == ref.view(np.uint64)).all(axis=1) | (np.isnan(got).any(axis=1) & np.isnan(ref).any(axis=1))
     assert same.all()
     backend.upload_scene(scene_of("cornell"))
+
+
+@pytest.mark.parametrize("keep", [[3, 4, 5, 6], [10], [5], [0, 10], [7, 3]])
+def test_small_scenes_cut_from_the_cornell_box(backend, pkg, oracle, scene_of, keep):
+    """Scenes of spheres only (no triangle at all), of the light alone, of one sphere, of one wall mesh and the light, of a box and a
+    sphere - with a background that shines, so that paths which leave the scene carry something: hits in every mode that serves the
+    scene and per-sample radiance equal the oracle's."""
+    base = scene_of("cornell")
+    objs = base.objects[keep].copy()
+    tris = []
+    first = 0
+    for k in range(len(objs)):
+        a, c = int(objs["first_triangle"][k]), int(objs["triangle_count"][k])
+        tris.append(base.triangles[a:a + c])
+        objs["first_triangle"][k] = first
+        first += c
+    flat = pkg.FlatScene(objs, np.concatenate(tris) if first else base.triangles[:0], (0.2, 0.3, 0.4))
+    sc = oracle.scene(flat)
+    rng = np.random.default_rng(5)
+    o = rng.uniform(-4.5, 4.5, (6000, 3)).astype(np.float32)
+    d = rng.normal(size=(6000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    want = oracle.intersect(sc, o, d)
+    for device_build in (False, True):
+        backend.upload_scene(flat, device_build=device_build)
+        for mode in (pkg.ACCEL_OCTREE, pkg.ACCEL_BRUTE, pkg.ACCEL_AUTO, pkg.ACCEL_FLAT, pkg.ACCEL_SCAN):
+            backend.set_accel(mode)
+            obj, elem, t = backend.intersect(o, d)
+            assert np.array_equal(obj, want[0]) and np.array_equal(elem, want[1]) and np.array_equal(t.view(np.uint32), want[2].view(np.uint32)), (device_build, mode)
+    backend.set_accel(pkg.ACCEL_AUTO)
+    cam = oracle.camera(40, 40, 90.0, POS, TGT)
+    backend.set_camera(cam)
+    px = rng.integers(0, 40 * 40, 400).astype(np.uint32)
+    sm = rng.integers(0, 500, 400).astype(np.uint32)
+    got = backend.trace_samples(px, sm, SEED, 100)
+    ref = oracle.trace_samples(sc, cam, px, sm, SEED, 100, portable_math=True, forward_sum=True)
+    assert np.array_equal(got.view(np.uint64), ref.view(np.uint64))
+    backend.clear(); backend.render(0, 9, 100, SEED)
+    img, _ = oracle.render(sc, cam, 0, 9, 100, SEED, threads=4, portable_math=True, forward_sum=True, lanes_per_pixel=backend.lanes_per_pixel(9))
+    assert np.array_equal(backend.read_accumulator(), img)
+    backend.upload_scene(scene_of("cornell"))
