@@ -195,3 +195,23 @@ def many_objects(cornell, meshes=120, tris_per_mesh=6, seed=7):
         v = [(centre + (t[k] - t["v0"]) * F(8.0) + shift).astype(F) for k in ("v0", "v1", "v2")]
         f = add_mesh(f, make_triangles(*v), tuple(float(x) for x in centre), material(color=0.3 + 0.005 * m))
     return f
+
+
+# --------------------------------------------------------------------- several lights
+def more_lights(base):
+    """`base` (a Cornell-box scene) with two more emitters: a sphere light of radius 0.4 and a point light (a sphere of radius 0,
+    source/scene.cpp:485-492).  Exercises the light loop of source/scene.cpp:127-141 with three lights of three kinds."""
+    n = len(base.objects)
+    objs = np.concatenate([base.objects, base.objects[3:5]]).copy()
+    for k, (pos, radius, emission) in enumerate([((-2.5, 2.0, 1.0), 0.4, (6.0, 4.0, 2.0)), ((2.0, 3.0, -1.0), 0.0, (3.0, 5.0, 8.0))]):
+        o = objs[n + k:n + k + 1]
+        o["kind"] = abi.OBJECT_SPHERE
+        o["first_triangle"] = 0
+        o["triangle_count"] = 0
+        o["radius"] = radius
+        o["position"] = pos
+        o["aabb_min"] = np.asarray(pos, F) - F(radius)
+        o["aabb_max"] = np.asarray(pos, F) + F(radius)
+        o["material"]["emission"] = emission
+        o["material"]["color"] = emission
+    return abi.FlatScene(objs, base.triangles.copy(), base.background)

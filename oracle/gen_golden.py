@@ -256,6 +256,15 @@ def main():
     scene_fixture(R, "cornell_sphere_light", ssc, sflat2, slights)
     hits_and_samples(R, "cornell_sphere_light", ssc, sflat2, cam512, np.random.default_rng(20261112), 2048)
 
+    # three emitters of three kinds (quad, sphere, point) in the config-3 scene: the light loop of source/scene.cpp:127-141
+    # (own generator: every other fixture keeps its bytes)
+    tflat = scenes.more_lights(scenes.config3(flat))
+    tsc = R.scene(tflat)
+    tflat2, tlights = R.dump(tsc)
+    assert len(tlights) == 3
+    scene_fixture(R, "three_lights", tsc, tflat2, tlights)
+    hits_and_samples(R, "three_lights", tsc, tflat2, cam512, np.random.default_rng(20261113), 2048)
+
     hexa = R.hexagon()
     hflat, hlights = R.dump(hexa)
     scene_fixture(R, "hexagon", hexa, hflat, hlights)

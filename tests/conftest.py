@@ -68,4 +68,4 @@ def backend(pkg):
     b.close()
 
 
-SCENES = ["cornell", "config2", "config3", "config4_2k", "hexagon", "cornell_point", "cornell_sphere_light"]
+SCENES = ["cornell", "config2", "config3", "config4_2k", "hexagon", "cornell_point", "cornell_sphere_light", "three_lights"]

@@ -495,3 +495,28 @@ def test_small_scenes_cut_from_the_cornell_box(backend, pkg, oracle, scene_of, k
     img, _ = oracle.render(sc, cam, 0, 9, 100, SEED, threads=4, portable_math=True, forward_sum=True, lanes_per_pixel=backend.lanes_per_pixel(9))
     assert np.array_equal(backend.read_accumulator(), img)
     backend.upload_scene(scene_of("cornell"))
+
+
+def test_several_lights(backend, pkg, oracle, scene_of):
+    """Three emitters (quad, sphere, point): the light loop of scene.cpp:127-141 - a point on EVERY light is drawn before the roulette
+    and the bounce, shadow rays one light after the other - per sample and as a render, in every mode, against the oracle."""
+    flat = scene_of("three_lights")            # scenes.more_lights(config3), as dumped by the reference
+    sc = oracle.scene(flat)
+    assert len(oracle.scene_lights(sc)) == 3
+    cam = oracle.camera(64, 48, 90.0, POS, TGT)
+    rng = np.random.default_rng(23)
+    px = rng.integers(0, 64 * 48, 600).astype(np.uint32)
+    sm = rng.integers(0, 1000, 600).astype(np.uint32)
+    ref = oracle.trace_samples(sc, cam, px, sm, SEED, 100, portable_math=True, forward_sum=True)
+    img, _ = oracle.render(sc, cam, 0, 6, 100, SEED, threads=8, portable_math=True, forward_sum=True, lanes_per_pixel=pkg.lanes_per_pixel(64, 48, 6))
+    backend.upload_scene(flat)
+    backend.set_camera(cam)
+    for mode in (pkg.ACCEL_AUTO, pkg.ACCEL_OCTREE, pkg.ACCEL_SCAN, pkg.ACCEL_BRUTE):
+        backend.set_accel(mode)
+        got = backend.trace_samples(px, sm, SEED, 100)
+        same = (got.view(np.uint64) == ref.view(np.uint64)).all(axis=1) | (np.isnan(got).any(axis=1) & np.isnan(ref).any(axis=1))
+        assert same.all(), mode
+        backend.clear(); backend.render(0, 6, 100, SEED)
+        assert np.array_equal(backend.read_accumulator(), img), mode
+    backend.set_accel(pkg.ACCEL_AUTO)
+    backend.upload_scene(scene_of("cornell"))
