@@ -215,3 +215,55 @@ def more_lights(base):
         o["material"]["emission"] = emission
         o["material"]["color"] = emission
     return abi.FlatScene(objs, base.triangles.copy(), base.background)
+
+
+# --------------------------------------------------------------------- random scenes (parity fuzzing)
+def add_sphere(flat, position, radius, mat=None):
+    """Append one SphereObject (source/objects/sphere.h:8-14)."""
+    o = np.zeros(1, abi.OBJECT_DTYPE)
+    o["kind"] = abi.OBJECT_SPHERE
+    o["radius"] = radius
+    o["position"] = np.asarray(position, F)
+    o["aabb_min"] = np.asarray(position, F) - F(radius)
+    o["aabb_max"] = np.asarray(position, F) + F(radius)
+    o["material"] = mat if mat is not None else material()
+    return abi.FlatScene(np.concatenate([flat.objects, o]), flat.triangles, flat.background)
+
+
+def random_scene(cornell, seed):
+    """The walls and the quad light of the Cornell box around a random population: spheres and small random meshes with materials
+    of every kind (Lambert / Oren-Nayar, mirror, glass), sometimes a second emitter (sphere or point).  Same generator, same scene."""
+    rng = np.random.default_rng([20261111, seed])
+    keep = [0, 1, 2, 10]
+    objs = cornell.objects[keep].copy()
+    tris, first = [], 0
+    for k in range(len(objs)):
+        a, c = int(objs["first_triangle"][k]), int(objs["triangle_count"][k])
+        tris.append(cornell.triangles[a:a + c])
+        objs["first_triangle"][k] = first
+        first += c
+    f = abi.FlatScene(objs, np.concatenate(tris), tuple(rng.uniform(0.0, 0.2, 3)) if seed % 2 else (0.0, 0.0, 0.0))
+
+    def mat():
+        kind = rng.integers(0, 6)
+        color = rng.uniform(0.2, 1.0, 3)
+        if kind == 0:
+            return material(color=color, surface=abi.SURFACE_SPECULAR)
+        if kind == 1:
+            return material(color=color, surface=abi.SURFACE_REFRACTIVE, ior=float(rng.uniform(1.1, 1.8)))
+        if kind in (2, 3):
+            return material(color=color, diffuse=abi.DIFFUSE_OREN_NAYAR, roughness=float(rng.uniform(0.05, 1.5)), albedo=float(rng.uniform(0.5, 1.0)))
+        return material(color=color, albedo=float(rng.uniform(0.5, 1.0)))
+
+    for _ in range(int(rng.integers(2, 9))):
+        f = add_sphere(f, rng.uniform(-3.5, 3.5, 3), float(rng.uniform(0.2, 1.4)), mat())
+    for _ in range(int(rng.integers(1, 7))):
+        n = int(rng.integers(1, 25))
+        centre = rng.uniform(-3.5, 3.5, 3).astype(F)
+        v = [(centre + rng.uniform(-1.2, 1.2, (n, 3))).astype(F) for _ in range(3)]
+        f = add_mesh(f, make_triangles(*v), tuple(float(x) for x in centre), mat())
+    extra = rng.integers(0, 3)
+    if extra:
+        f = add_sphere(f, rng.uniform(-3.0, 3.0, 3), 0.0 if extra == 1 else float(rng.uniform(0.2, 0.6)),
+                       material(color=(4.0, 5.0, 6.0), emission=(4.0, 5.0, 6.0)))
+    return f

@@ -520,3 +520,41 @@ def test_several_lights(backend, pkg, oracle, scene_of):
         assert np.array_equal(backend.read_accumulator(), img), mode
     backend.set_accel(pkg.ACCEL_AUTO)
     backend.upload_scene(scene_of("cornell"))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scenes(backend, pkg, oracle, scene_of, seed):
+    """scenes.random_scene: spheres and small meshes with every kind of material, sometimes a second emitter (the oracle equals the
+    compiled reference on these, tests/test_oracle_golden.py): hits in every mode, host- and device-built octree, per-sample radiance
+    and a small render against the oracle."""
+    from mcrt_amd import scenes
+
+    flat = scenes.random_scene(scene_of("cornell"), seed)
+    sc = oracle.scene(flat)
+    rng = np.random.default_rng(100 + seed)
+    o = rng.uniform(-4.5, 4.5, (8000, 3)).astype(np.float32)
+    d = rng.normal(size=(8000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    want = oracle.intersect(sc, o, d)
+    cam = oracle.camera(48, 36, 90.0, POS, TGT)
+    px = rng.integers(0, 48 * 36, 500).astype(np.uint32)
+    sm = rng.integers(0, 1 << 16, 500).astype(np.uint32)
+    ref = oracle.trace_samples(sc, cam, px, sm, SEED, 100, portable_math=True, forward_sum=True)
+    img, _ = oracle.render(sc, cam, 0, 5, 100, SEED, threads=8, portable_math=True, forward_sum=True, lanes_per_pixel=pkg.lanes_per_pixel(48, 36, 5))
+    for device_build in (False, True):
+        backend.upload_scene(flat, device_build=device_build)
+        backend.set_camera(cam)
+        for mode in (pkg.ACCEL_AUTO, pkg.ACCEL_OCTREE, pkg.ACCEL_SCAN, pkg.ACCEL_BRUTE):
+            backend.set_accel(mode)
+            obj, elem, t = backend.intersect(o, d)
+            assert np.array_equal(obj, want[0]) and np.array_equal(elem, want[1]) and np.array_equal(t.view(np.uint32), want[2].view(np.uint32)), (device_build, mode)
+            if device_build and mode != pkg.ACCEL_OCTREE:
+                continue
+            got = backend.trace_samples(px, sm, SEED, 100)
+            same = (got.view(np.uint64) == ref.view(np.uint64)).all(axis=1) | (np.isnan(got).any(axis=1) & np.isnan(ref).any(axis=1))
+            assert same.all(), (device_build, mode, int((~same).sum()))
+            backend.clear(); backend.render(0, 5, 100, SEED)
+            acc = backend.read_accumulator()
+            assert np.array_equal(acc, img) or (np.isnan(img).any() and np.array_equal(np.isnan(acc), np.isnan(img))), (device_build, mode)
+    backend.set_accel(pkg.ACCEL_AUTO)
+    backend.upload_scene(scene_of("cornell"))

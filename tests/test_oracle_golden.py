@@ -153,3 +153,28 @@ def test_oracle_slice_order_is_what_the_header_says(oracle, scene_of):
                     part = part + row
                 tot = part if tot is None else tot + part
             assert np.array_equal(got.reshape(-1, 3)[p], start.reshape(-1, 3)[p] + tot), (lanes, p)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_oracle_against_live_reference_on_random_scenes(oracle, ref, scene_of, seed):
+    """Random populations of spheres and meshes with every kind of material, with and without a second emitter: hits and per-sample
+    radiance of the restatement equal the reference's own, bit for bit."""
+    from mcrt_amd import scenes
+
+    flat = scenes.random_scene(scene_of("cornell"), seed)
+    rng = np.random.default_rng(100 + seed)
+    o = rng.uniform(-4.5, 4.5, (4000, 3)).astype(np.float32)
+    d = rng.normal(size=(4000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    a = ref.intersect(ref.scene(flat), o, d)
+    b = oracle.intersect(oracle.scene(flat), o, d)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    cam_r = ref.camera(128, 96, 90.0, (0, 0, 5), (0, 0, 0))
+    cam_o = oracle.camera(128, 96, 90.0, (0, 0, 5), (0, 0, 0))
+    px = rng.integers(0, 128 * 96, 1500).astype(np.uint32)
+    sm = rng.integers(0, 1 << 16, 1500).astype(np.uint32)
+    ra = ref.trace_samples(ref.scene(flat), cam_r, px, sm, 4242, 100)
+    rb = oracle.trace_samples(oracle.scene(flat), cam_o, px, sm, 4242, 100)
+    same = (ra.view(np.uint64) == rb.view(np.uint64)).all(axis=1) | (np.isnan(ra).any(axis=1) & np.isnan(rb).any(axis=1))
+    assert same.all(), f"{(~same).sum()} of {len(same)} samples differ"
