@@ -558,3 +558,38 @@ def test_random_scenes(backend, pkg, oracle, scene_of, seed):
             assert np.array_equal(acc, img) or (np.isnan(img).any() and np.array_equal(np.isnan(acc), np.isnan(img))), (device_build, mode)
     backend.set_accel(pkg.ACCEL_AUTO)
     backend.upload_scene(scene_of("cornell"))
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_big_random_scenes_walked_from_hbm(pkg, oracle, scene_of, seed, monkeypatch):
+    """A random scene plus two triangle soups of glass and mirror (3000 + 1500 triangles: the octree image lives in HBM), so that the
+    free-running-lane kernel and the wavefront pipeline both park refractive branches while they walk: renders and per-sample radiance
+    against the oracle (brute force on the CPU)."""
+    from mcrt_amd import scenes
+
+    flat = scenes.random_scene(scene_of("cornell"), 50 + seed)
+    flat = scenes.add_mesh(flat, scenes.random_mesh_triangles(3000, 11 + seed), (0.0, 0.0, 0.0), scenes.material(color=0.9, surface=pkg.abi.SURFACE_REFRACTIVE, ior=1.3))
+    flat = scenes.add_mesh(flat, scenes.random_mesh_triangles(1500, 31 + seed), (0.0, 0.0, 0.0), scenes.material(color=0.8, surface=pkg.abi.SURFACE_SPECULAR))
+    sc = oracle.scene(flat)
+    cam = oracle.camera(40, 30, 90.0, POS, TGT)
+    rng = np.random.default_rng(seed)
+    px = rng.integers(0, 40 * 30, 400).astype(np.uint32)
+    sm = rng.integers(0, 1 << 16, 400).astype(np.uint32)
+    ref = oracle.trace_samples(sc, cam, px, sm, SEED, 100, portable_math=True, forward_sum=True)
+    img, _ = oracle.render(sc, cam, 2, 6, 100, SEED, threads=8, portable_math=True, forward_sum=True, lanes_per_pixel=pkg.lanes_per_pixel(40, 30, 6))
+    for wavefront in ("0", "1"):
+        monkeypatch.setenv("MCRT_WAVEFRONT", wavefront)
+        b = pkg.Backend(0)
+        try:
+            b.upload_scene(flat, device_build=bool(seed % 2))
+            assert not b.octree_info().lds_resident
+            b.set_camera(cam)
+            got = b.trace_samples(px, sm, SEED, 100)
+            same = (got.view(np.uint64) == ref.view(np.uint64)).all(axis=1) | (np.isnan(got).any(axis=1) & np.isnan(ref).any(axis=1))
+            assert same.all(), (wavefront, int((~same).sum()))
+            b.clear(); b.render(2, 6, 100, SEED)
+            acc = b.read_accumulator()
+            assert np.array_equal(acc, img) or (np.isnan(img).any() and np.array_equal(np.isnan(acc), np.isnan(img))), wavefront
+        finally:
+            b.close()
+    monkeypatch.delenv("MCRT_WAVEFRONT")
