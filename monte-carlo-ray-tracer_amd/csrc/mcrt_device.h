@@ -614,69 +614,68 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
             // all three loads in one round trip: without this the compiler sinks the third into the `mask != 0` branch, behind the tight test
             asm volatile("" ::"v"(rc.x), "v"(rc.y), "v"(rc.z), "v"(rc.w));
             if (kCount) cn.nodes++;
+            // the node's own tight box against [0, best.t]: [tb0, tb1] is the stretch of the ray inside it
+            float tb0 = 0.0f, tb1 = best.t;
             {
-                // the node's own tight box against [0, best.t]
-                float t0 = 0.0f, t1 = best.t;
                 float p = (__uint_as_float(ra.x) - o.x) * inv.x, q = (__uint_as_float(ra.w) - o.x) * inv.x;
-                t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
+                tb0 = fmaxf(tb0, fminf(p, q)); tb1 = fminf(tb1, fmaxf(p, q));
                 p = (__uint_as_float(ra.y) - o.y) * inv.y; q = (__uint_as_float(rb.x) - o.y) * inv.y;
-                t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
+                tb0 = fmaxf(tb0, fminf(p, q)); tb1 = fminf(tb1, fmaxf(p, q));
                 p = (__uint_as_float(ra.z) - o.z) * inv.z; q = (__uint_as_float(rb.y) - o.z) * inv.z;
-                t0 = fmaxf(t0, fminf(p, q)); t1 = fminf(t1, fmaxf(p, q));
-                if (!(t0 <= t1)) return;
+                tb0 = fmaxf(tb0, fminf(p, q)); tb1 = fminf(tb1, fmaxf(p, q));
+                if (!(tb0 <= tb1)) return;
             }
             pleaf = rb.w;
             const uint32_t cw = rb.z, mask = cw >> 24;
             if (mask) {
                 const uint32_t base = cw & 0x00FFFFFFu;
                 const float scale = __uint_as_float(rc.w);
-                // per axis: entry / exit distances of the near half [near face - pad, mid + pad] and the far half [mid - pad, far face + pad]
-                float n_in[3], n_out[3], f_in[3], f_out[3];
+                // Which octants, in which order?  A straight line meets each of the cell's three mid planes once, so inside [tb0, tb1] it
+                // passes at most four octants: the one it is in at tb0 and one more per mid plane crossed (Revelles' parametric walk).
+                // In ray order (bit a of r set = beyond the mid plane of axis a): r starts with the planes already behind at tb0; every
+                // plane crossed before tb1 flips its bit, nearest crossing first.  Everything is decided with the padding on the
+                // generous side: a plane counts as behind only when it is more than the padding behind, as crossed when it comes within
+                // the padding of [tb0, tb1], and the octant beyond it is entered the padding early.  A hit point always lies in the padded
+                // cell of the octant that is current at its distance (per axis it is on the same side of the mid plane or within the
+                // padding of it), and the builder references a primitive from every child whose padded cell it overlaps - so the
+                // primitive is met there, and the entry distance is not behind it (ties included).  The octant test this replaces
+                // worked out all eight padded boxes (max3 / min3 / compare each) and pushed in a loop: ~225 instructions, now ~90.
                 const float cmn[3] = { __uint_as_float(rc.x), __uint_as_float(rc.y), __uint_as_float(rc.z) };
                 const float oo[3] = { o.x, o.y, o.z }, ii[3] = { inv.x, inv.y, inv.z }, pp[3] = { padt.x, padt.y, padt.z }, dd[3] = { dts.x, dts.y, dts.z };
+                uint32_t r0 = 0;
+                float c[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    // the three planes of an axis from ONE subtraction: the cell is the root cell scaled by 2^-depth, so the ray needs
-                    // dts * scale from face to face and half of that to the mid plane (against (plane - o) * inv that is a few ulps of t;
-                    // the padding is 256 ulps of the largest coordinate at least)
-                    const float t_lo = (cmn[k] - oo[k]) * ii[k];
-                    const float dt = dd[k] * scale;
-                    const float t_hi = t_lo + dt;
-                    const float tm = __fmaf_rn(dt, 0.5f, t_lo);
-                    const float tn = fminf(t_lo, t_hi), tf = fmaxf(t_lo, t_hi);
-                    n_in[k] = tn - pp[k]; n_out[k] = tm + pp[k];
-                    f_in[k] = tm - pp[k]; f_out[k] = tf + pp[k];
+                    // the mid plane from the cell's corner: the cell is the root cell scaled by 2^-depth, half of dts * scale away
+                    const float tm = __fmaf_rn(dd[k] * scale, 0.5f, (cmn[k] - oo[k]) * ii[k]);
+                    const float enter = tm - pp[k];                       // where the half beyond the plane begins for this ray
+                    const bool behind = enter < tb0 - 2.0f * pp[k] ? true : false;      // tm < tb0 - pad
+                    r0 |= behind ? (1u << k) : 0u;
+                    c[k] = (!behind && enter <= tb1) ? enter : __builtin_inff();
                 }
-                // The eight octants in ray order (bit a of k clear = the half the ray meets first on axis a): first WHICH of them the
-                // ray passes, as one 8-bit mask without a branch - [0, best.t] is folded into the x intervals, an octant is three
-                // interval bounds: max3 / min3 / compare -, then one push per set bit, far octants first.  (Eight predicated
-                // push blocks cost the wavefront 8 x ~22 instructions and as many branches whatever the rays do; a ray passes
-                // two or three octants.)
-                n_in[0] = fmaxf(n_in[0], 0.0f); f_in[0] = fmaxf(f_in[0], 0.0f);
-                n_out[0] = fminf(n_out[0], best.t); f_out[0] = fminf(f_out[0], best.t);
-                // existing children, permuted into ray order: bit k of `have` = bit (k ^ flip) of mask
-                uint32_t have = mask;
-                if (flip & 1u) have = ((have & 0x55u) << 1) | ((have >> 1) & 0x55u);
-                if (flip & 2u) have = ((have & 0x33u) << 2) | ((have >> 2) & 0x33u);
-                if (flip & 4u) have = ((have & 0x0Fu) << 4) | ((have >> 4) & 0x0Fu);
-                uint32_t hitmask = 0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float t0 = fmaxf(fmaxf((k & 1) ? f_in[0] : n_in[0], (k & 2) ? f_in[1] : n_in[1]), (k & 4) ? f_in[2] : n_in[2]);
-                    const float t1 = fminf(fminf((k & 1) ? f_out[0] : n_out[0], (k & 2) ? f_out[1] : n_out[1]), (k & 4) ? f_out[2] : n_out[2]);
-                    hitmask |= (t0 <= t1) ? (1u << k) : 0u;
+                // the three crossings in order (a three-element sorting network; the axis bit travels with its distance)
+                float k0 = c[0], k1 = c[1], k2 = c[2];
+                uint32_t b0 = 1u, b1 = 2u, b2 = 4u;
+                if (k1 < k0) { const float t = k0; k0 = k1; k1 = t; const uint32_t u = b0; b0 = b1; b1 = u; }
+                if (k2 < k1) { const float t = k1; k1 = k2; k2 = t; const uint32_t u = b1; b1 = b2; b2 = u; }
+                if (k1 < k0) { const float t = k0; k0 = k1; k1 = t; const uint32_t u = b0; b0 = b1; b1 = u; }
+                const uint32_t r1 = r0 ^ b0, r2 = r1 ^ b1, r3 = r2 ^ b2;
+                // far to near; an octant whose entry lies behind the best hit so far (or that is not entered at all: +inf) is left out
+                const bool fast = st.room(sp, 4);
+#define MCRT_PUSH_OCTANT(R, T)                                                                   \
+                {                                                                                    \
+                    const uint32_t oct = (R) ^ flip;                                                 \
+                    if ((mask >> oct) & 1u) {                                                        \
+                        const uint32_t child = base + __popc(mask & ((1u << oct) - 1u));             \
+                        if (fast) st.put_fast(sp, (T), child); else st.put(sp, (T), child);          \
+                        ++sp;                                                                        \
+                    }                                                                                \
                 }
-                hitmask &= have;
-                const bool fast = st.room(sp, 8);
-                while (hitmask) {
-                    const uint32_t k = 31u - (uint32_t)__clz((int)hitmask);      // the farthest octant left
-                    hitmask ^= 1u << k;
-                    const float t0 = fmaxf(fmaxf((k & 1u) ? f_in[0] : n_in[0], (k & 2u) ? f_in[1] : n_in[1]), (k & 4u) ? f_in[2] : n_in[2]);
-                    const uint32_t oct = k ^ flip;
-                    const uint32_t child = base + __popc(mask & ((1u << oct) - 1u));
-                    if (fast) st.put_fast(sp, t0, child); else st.put(sp, t0, child);
-                    ++sp;
-                }
+                if (k2 <= best.t) MCRT_PUSH_OCTANT(r3, fmaxf(tb0, k2))
+                if (k1 <= best.t) MCRT_PUSH_OCTANT(r2, fmaxf(tb0, k1))
+                if (k0 <= best.t) MCRT_PUSH_OCTANT(r1, fmaxf(tb0, k0))
+                MCRT_PUSH_OCTANT(r0, tb0)
+#undef MCRT_PUSH_OCTANT
             }
         }
 
