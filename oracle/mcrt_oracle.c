@@ -724,37 +724,41 @@ static hit_t octree_hit(const orc_scene* S, const orc_octree* T, const uint32_t*
         uint32_t node = stack_node[sp];
         if (stack_t[sp] > best.t) continue;
         if (st) st->nodes++;
+        float tb0 = 0.0f, tb1 = best.t;         /* the stretch of the ray inside the node's tight box */
         {
             const float* b = T->box + 6 * (size_t)node;
-            float t0 = 0.0f, t1 = best.t;
             for (int a = 0; a < 3; ++a) {
                 float x = (b[a] - oo[a]) * inv[a], y = (b[3 + a] - oo[a]) * inv[a];
-                t0 = fmaxf(t0, fminf(x, y)); t1 = fminf(t1, fmaxf(x, y));
+                tb0 = fmaxf(tb0, fminf(x, y)); tb1 = fminf(tb1, fmaxf(x, y));
             }
-            if (!(t0 <= t1)) continue;
+            if (!(tb0 <= tb1)) continue;
         }
         uint32_t cw = T->words[2 * (size_t)node];
         uint32_t base = cw & 0x00FFFFFFu, mask = cw >> 24;
         if (mask) {
+            /* OctreeWalk::visit, csrc/mcrt_device.h: the octant the ray is in at tb0 plus one per mid plane crossed before tb1, in ray
+               order (bit a of r set = beyond the mid plane of axis a), every decision padded on the generous side */
             const float* cell = T->cell + 4 * (size_t)node;
-            float n_in[3], n_out[3], f_in[3], f_out[3];
+            uint32_t r0 = 0;
+            float k[3]; uint32_t bit[3] = { 1u, 2u, 4u };
             for (int a = 0; a < 3; ++a) {
-                const float size = root_size[a] * cell[3];
-                const float mid = cell[a] + 0.5f * size, cmx = cell[a] + size;
-                const int back = (flip >> a) & 1u;
-                const float tn = ((back ? cmx : cell[a]) - oo[a]) * inv[a];
-                const float tm = (mid - oo[a]) * inv[a];
-                const float tf = ((back ? cell[a] : cmx) - oo[a]) * inv[a];
-                n_in[a] = tn - padt[a]; n_out[a] = tm + padt[a];
-                f_in[a] = tm - padt[a]; f_out[a] = tf + padt[a];
+                const float tm = fmaf(root_size[a] * inv[a] * cell[3], 0.5f, (cell[a] - oo[a]) * inv[a]);
+                const float enter = tm - padt[a];
+                const int behind = enter < tb0 - 2.0f * padt[a];
+                if (behind) r0 |= 1u << a;
+                k[a] = (!behind && enter <= tb1) ? enter : INFINITY;
             }
-            for (int k = 7; k >= 0; --k) {
-                const float t0 = fmaxf(fmaxf((k & 1) ? f_in[0] : n_in[0], (k & 2) ? f_in[1] : n_in[1]), fmaxf((k & 4) ? f_in[2] : n_in[2], 0.0f));
-                const float t1 = fminf(fminf((k & 1) ? f_out[0] : n_out[0], (k & 2) ? f_out[1] : n_out[1]), fminf((k & 4) ? f_out[2] : n_out[2], best.t));
-                const uint32_t oct = (uint32_t)k ^ flip;
-                if (!(mask & (1u << oct)) || !(t0 <= t1)) continue;
+#define ORC_CSWAP(i, j) if (k[j] < k[i]) { float t_ = k[i]; k[i] = k[j]; k[j] = t_; uint32_t u_ = bit[i]; bit[i] = bit[j]; bit[j] = u_; }
+            ORC_CSWAP(0, 1) ORC_CSWAP(1, 2) ORC_CSWAP(0, 1)
+#undef ORC_CSWAP
+            const uint32_t r[4] = { r0, r0 ^ bit[0], r0 ^ bit[0] ^ bit[1], r0 ^ bit[0] ^ bit[1] ^ bit[2] };
+            for (int j = 3; j >= 0; --j) {
+                const float t_in = j ? fmaxf(tb0, k[j - 1]) : tb0;
+                if (j && !(k[j - 1] <= best.t)) continue;
+                const uint32_t oct = r[j] ^ flip;
+                if (!(mask & (1u << oct))) continue;
                 const uint32_t child = base + (uint32_t)__builtin_popcount(mask & ((1u << oct) - 1u));
-                if (sp < STACK) { stack_node[sp] = child; stack_t[sp] = t0; ++sp; } else *overflow = 1;
+                if (sp < STACK) { stack_node[sp] = child; stack_t[sp] = t_in; ++sp; } else *overflow = 1;
             }
         }
         uint32_t ref = T->words[2 * (size_t)node + 1];
