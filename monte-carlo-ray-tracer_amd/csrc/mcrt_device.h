@@ -626,6 +626,13 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
                 if (!(tb0 <= tb1)) return;
             }
             pleaf = rb.w;
+            if (pleaf != NO_REFS) {
+                // the node's own list: its first record travels while the octants are worked out
+                const uint32_t r = pleaf * LEAF_STRIDE;
+                a = ld4(leaves, r); b = ld4(leaves, r + 4); c = ld4(leaves, r + 8);
+                asm volatile("" ::: "memory");
+                loaded = true;
+            }
             const uint32_t cw = rb.z, mask = cw >> 24;
             if (mask) {
                 const uint32_t base = cw & 0x00FFFFFFu;
