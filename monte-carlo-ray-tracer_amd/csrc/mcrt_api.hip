@@ -156,8 +156,7 @@ static_assert(LDS_STACK_BLOCK == kBlock, "LdsStack columns are one per thread of
 // Scheduling knobs of trace_lane (wave-uniform runtime values, so that they can be swept without rebuilding):
 //   min_trace   lanes with a camera / bounce ray are served when at least this many are waiting (0: always)
 //   fetch_min   idle lanes fetch their next items together once this many are idle (1: at once)
-//   refill      octree walk: bits 0..7: hand back control once fewer than refill/64 of the lanes that entered are still walking
-//               (0: walk to the end); bits 8..: leaf records per visit (OctreeWalk::visit)
+//   refill      octree walk: hand back control once fewer than refill/64 of the lanes that entered are still walking (0: walk to the end)
 struct LanePolicy { uint32_t min_trace, fetch_min, refill; };
 
 enum : uint32_t { ST_NEW = 0, ST_TRACE = 1, ST_SHADOW = 2, ST_DONE = 3, ST_FETCH = 4 };
@@ -494,7 +493,7 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
             if constexpr (kWalk) {
                 // a lane without a ray has an empty stack: it sits in the walk loop as a finished lane
                 if (live && !walking) { walk.begin(sm, v, walk_stack, ln.ro, ln.rd, cn); walking = true; }
-                walk.run(sm, big, v, walk_stack, ln.ro, ln.rd, cn, policy.refill & 0xFFu, policy.refill >> 8);
+                walk.run(sm, big, v, walk_stack, ln.ro, ln.rd, cn, policy.refill);
                 if (!live || !walk.done()) continue;          // no ray, or still in mid-traversal: nothing to shade yet
                 walking = false;
                 hit = walk.best;
@@ -862,7 +861,7 @@ __global__ __launch_bounds__(kBlock, kBlocksPerCu) void k_wf_trace(const WfArgs 
             need = __ballot(mine && !take);
         }
         if (__ballot(!walk.done()) == 0ull) break;     // nobody walks: every lane has stored its hit and found the queue empty
-        if (!walk.done()) walk.visit(sm, nodes, leaves, v, st, o, d, inv, padt, dts, flip, 4u, cn);
+        if (!walk.done()) walk.visit(sm, nodes, leaves, v, st, o, d, inv, padt, dts, flip, cn);
     }
     if (kCount) flush_counters(a.r.counters, cn, rc);
 }
@@ -1109,7 +1108,6 @@ struct mcrt_ctx {
     int min_trace_override = -1;                // MCRT_MIN_TRACE (tuning knob): LanePolicy::min_trace
     int fetch_min_override = -1;                // MCRT_FETCH_MIN (tuning knob): LanePolicy::fetch_min
     int refill_override = -1;                   // MCRT_REFILL (tuning knob): LanePolicy::refill, threshold
-    int chunk_override = 0;                     // MCRT_LEAF_CHUNK (tuning knob): LanePolicy::refill, leaf records per visit
     uint32_t wave_slices = 64;                  // MCRT_WAVE_SLICES (tuning knob): slices of a pixel that share a wavefront, at most
 
     // wavefront pipeline (k_wf_shade / k_wf_trace): path-slot state, hits, the two slot queues, counters
@@ -1405,8 +1403,7 @@ LanePolicy lane_policy(const mcrt_ctx* c)
     // measured (profiles/r01_refill_sweep.txt): refilling pays when the image is walked from HBM/L2 (long, exponentially distributed
     // walks); with an LDS-resident image the extra shading passes cost more than they save
     const uint32_t refill = c->refill_override >= 0 ? (uint32_t)c->refill_override : (c->big_in_lds ? 0u : 40u);
-    const uint32_t chunk = c->chunk_override > 0 ? (uint32_t)c->chunk_override : (c->big_in_lds ? 0xFFFFFFu : 4u);
-    p.refill = refill | (chunk << 8);
+    p.refill = refill;
     return p;
 }
 
@@ -1497,7 +1494,6 @@ int mcrt_create(int device_id, mcrt_ctx** out_ctx)
     if (const char* e = getenv("MCRT_MIN_TRACE")) { int r = atoi(e); if (r >= 0 && r <= 64) c->min_trace_override = r; }
     if (const char* e = getenv("MCRT_GRID_MULT")) { int r = atoi(e); if (r >= 1 && r <= 16) c->grid_mult = (uint32_t)r; }
     if (const char* e = getenv("MCRT_REFILL")) { int r = atoi(e); if (r >= 0 && r <= 64) c->refill_override = r; }
-    if (const char* e = getenv("MCRT_LEAF_CHUNK")) { int r = atoi(e); if (r > 0 && r < (1 << 20)) c->chunk_override = r; }
     if (const char* e = getenv("MCRT_FETCH_MIN")) { int r = atoi(e); if (r >= 1 && r <= 64) c->fetch_min_override = r; }
     if (const char* e = getenv("MCRT_WAVE_SLICES")) { int r = atoi(e); if (r >= 1 && r <= 64) c->wave_slices = (uint32_t)r; }
     if (const char* e = getenv("MCRT_WAVEFRONT")) { int r = atoi(e); if (r == 0 || r == 1) c->wavefront = r; }

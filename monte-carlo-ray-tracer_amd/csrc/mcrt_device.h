@@ -486,15 +486,13 @@ MCRT_DEV void wave_sync()
 //   pop      the nearest stack entry not behind the best hit so far: (entry distance, node index);
 //   fetch    the node's 48-byte record (three 16-byte loads issued together) and test its tight box;
 //   descend  which of the node's octants does the ray pass, and where does it enter them?  That follows from the
-//            node's CELL alone - its faces and three mid planes, nine plane distances - so no child record is
-//            touched: octants are entered through cells widened by the builder's padding (a primitive is referenced
-//            from every cell that contains a point of it, so the cell that contains the hit point is always among
-//            them, rounding included), pushed far to near.  A ray passes at most four octants of a cell unless it
-//            runs within the padding of its centre; the old walk fetched and slab-tested all eight child boxes of
-//            every visited node (256 bytes and sixteen loads a visit: 2.2x the algorithmic traffic);
-//   leaves   at most `chunk` records of the node's list (streamed, the next record requested before the current one
-//            is tested); a longer list re-queues its rest on top of the stack, so that the other lanes of the
-//            wavefront wait for `chunk` records, not for the longest list among 64 nodes.
+//            node's own record - the stretch of the ray inside its tight box and the three mid planes of its CELL - so no
+//            child record is touched (the first walk fetched and slab-tested all eight child boxes of every visited node:
+//            256 bytes and sixteen loads a visit, 2.2x the algorithmic traffic): at most four octants, the one the ray is in
+//            when it enters plus one per mid plane crossed, padded on the generous side (see visit()), pushed far to near;
+//   leaves   ONE record of the list the lane is working off per step (the record of a list that has just begun is requested while
+//            the octants are worked out): the other lanes of the wavefront wait for one record, never for the longest list among
+//            64 nodes (two records per step measured 9 % slower, four 29 %).
 // The walk is RESUMABLE: run() returns to the caller as soon as enough lanes of the wavefront have finished their
 // ray, the caller shades those lanes, gives them their next ray and calls run() again; lanes in mid-traversal simply
 // carry on.  Ray lengths in a big scene are close to exponentially distributed, so a wavefront that waits for its
@@ -591,7 +589,7 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
     // inv: clamped reciprocals of the direction; padt = pad * |inv| per axis; dts = root cell size * inv per axis; flip: bit a set where the ray runs
     // towards smaller coordinates on axis a (sign of inv, so that +-0 components are treated consistently).
     template <class St> MCRT_DEV void visit(PS sm, PB nodes, PB leaves, const SceneView& v, St& st, V3 o, V3 d, V3 inv, V3 padt, V3 dts, uint32_t flip,
-                        uint32_t, Counters& cn)
+                        Counters& cn)
     {
         U4 a, b, c;
         bool loaded = false;
@@ -743,7 +741,7 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
 
     // Advance every unfinished lane.  refill == 0: until all lanes of the wavefront are finished; otherwise
     // return once fewer than refill/64 of the lanes that came in unfinished are still walking.
-    template <class St> MCRT_DEV void run(PS sm, PB big, const SceneView& v, St& st, V3 o, V3 d, Counters& cn, uint32_t refill, uint32_t chunk = 0xFFFFFFFFu)
+    template <class St> MCRT_DEV void run(PS sm, PB big, const SceneView& v, St& st, V3 o, V3 d, Counters& cn, uint32_t refill)
     {
         V3 inv, padt, dts;
         uint32_t flip;
@@ -755,7 +753,7 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
         for (;;) {
             const uint32_t walking = (uint32_t)__popcll(__ballot(!done()));
             if (walking == 0 || walking < keep) break;
-            if (!done()) visit(sm, nodes, leaves, v, st, o, d, inv, padt, dts, flip, chunk, cn);
+            if (!done()) visit(sm, nodes, leaves, v, st, o, d, inv, padt, dts, flip, cn);
         }
     }
 };
