@@ -409,8 +409,9 @@ inline int build_on_device(hipStream_t stream, const Params& P, const uint32_t* 
     BLD_TRY(hipMemsetAsync(counter.p, 0, 16, stream));
     hipLaunchKernelGGL(k_bld_boxes, dim3(blocks_for(P.nprim)), dim3(kThreads), 0, stream, P, d_small, off_obj, raw.p, pbox.p, prim_obj.p, skip.p, rootbox.p);
 
-    // node arrays: capacity 4 nodes per primitive (the 1M-triangle soup needs 2.4), checked level by level
-    const size_t cap = (size_t)P.nprim * 4 + 4096;
+    // node arrays: 4 nodes per primitive to begin with (the 1M-triangle soup needs 2.4), grown level by level when a scene needs more
+    // (one whose padding is large against its cells - far from the origin, say - references a primitive from many of them)
+    size_t cap = (size_t)P.nprim * 4 + 4096;
     Buf<float> cell; Buf<int> tight; Buf<uint32_t> depth, begin, count, own_begin, own_count, child_word;
     BLD_TRY(cell.alloc(cap * 6)); BLD_TRY(tight.alloc(cap * 6)); BLD_TRY(depth.alloc(cap)); BLD_TRY(begin.alloc(cap)); BLD_TRY(count.alloc(cap));
     BLD_TRY(own_begin.alloc(cap)); BLD_TRY(own_count.alloc(cap)); BLD_TRY(child_word.alloc(cap));
@@ -469,7 +470,25 @@ inline int build_on_device(hipStream_t stream, const Params& P, const uint32_t* 
         BLD_TRY(hipMemcpyAsync(&tot[2], own_off.p + ln, 4, hipMemcpyDeviceToHost, stream));
         BLD_TRY(hipStreamSynchronize(stream));
         const uint32_t next_nodes = tot[0], next_members = tot[1], level_refs = tot[2];
-        if ((size_t)total_nodes + next_nodes > cap || (size_t)total_nodes + next_nodes >= (1u << 24)) { err = "device octree build: node capacity exceeded"; return 1; }
+        if ((size_t)total_nodes + next_nodes >= (1u << 24)) { err = "device octree build: more than 2^24 nodes"; return 1; }
+        if ((size_t)total_nodes + next_nodes > cap) {
+            const size_t new_cap = std::max(cap * 2, (size_t)total_nodes + next_nodes + 4096);
+            auto grow = [&](auto& buf, size_t per_node) -> hipError_t {
+                typename std::remove_reference<decltype(buf)>::type bigger;
+                hipError_t e = bigger.alloc(new_cap * per_node);
+                if (e != hipSuccess) return e;
+                e = hipMemcpyAsync(bigger.p, buf.p, (size_t)total_nodes * per_node * sizeof(*buf.p), hipMemcpyDeviceToDevice, stream);
+                if (e != hipSuccess) return e;
+                e = hipStreamSynchronize(stream);
+                if (e != hipSuccess) return e;
+                std::swap(buf.p, bigger.p); std::swap(buf.n, bigger.n);      // `bigger` frees the old array
+                return hipSuccess;
+            };
+            BLD_TRY(grow(cell, 6)); BLD_TRY(grow(tight, 6)); BLD_TRY(grow(depth, 1)); BLD_TRY(grow(begin, 1)); BLD_TRY(grow(count, 1));
+            BLD_TRY(grow(own_begin, 1)); BLD_TRY(grow(own_count, 1)); BLD_TRY(grow(child_word, 1));
+            N = Nodes{ cell.p, tight.p, depth.p, begin.p, count.p, own_begin.p, own_count.p, child_word.p };
+            cap = new_cap;
+        }
         const int nxt = cur ^ 1;
         if (mem_prim[nxt].p) { (void)hipFree(mem_prim[nxt].p); mem_prim[nxt].p = nullptr; (void)hipFree(mem_node[nxt].p); mem_node[nxt].p = nullptr; }
         BLD_TRY(mem_prim[nxt].alloc(next_members)); BLD_TRY(mem_node[nxt].alloc(next_members));

@@ -267,3 +267,21 @@ def random_scene(cornell, seed):
         f = add_sphere(f, rng.uniform(-3.0, 3.0, 3), 0.0 if extra == 1 else float(rng.uniform(0.2, 0.6)),
                        material(color=(4.0, 5.0, 6.0), emission=(4.0, 5.0, 6.0)))
     return f
+
+
+def transformed(base, scale, shift):
+    """`base` scaled about the origin and moved by `shift` along every axis, in float arithmetic; mesh boxes re-made from the rounded
+    vertices as TriangleMesh::UpdateAABB does.  (Normals stay: a uniform scale and a translation do not turn them.)"""
+    objs, tris = base.objects.copy(), base.triangles.copy()
+    for k in ("v0", "v1", "v2"):
+        tris[k] = (tris[k] * F(scale) + F(shift)).astype(F)
+    for k in ("position", "aabb_min", "aabb_max"):
+        objs[k] = (objs[k] * F(scale) + F(shift)).astype(F)
+    for k in ("radius", "light_x", "light_y"):
+        objs[k] = (objs[k] * F(scale)).astype(F)
+    for i in range(len(objs)):
+        a, c = int(objs["first_triangle"][i]), int(objs["triangle_count"][i])
+        if c:
+            pts = np.concatenate([tris[k][a:a + c] for k in ("v0", "v1", "v2")] + [objs["position"][i:i + 1]])
+            objs["aabb_min"][i], objs["aabb_max"][i] = pts.min(axis=0), pts.max(axis=0)
+    return abi.FlatScene(objs, tris, base.background)

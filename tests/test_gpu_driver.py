@@ -593,3 +593,40 @@ def test_big_random_scenes_walked_from_hbm(pkg, oracle, scene_of, seed, monkeypa
         finally:
             b.close()
     monkeypatch.delenv("MCRT_WAVEFRONT")
+
+
+@pytest.mark.parametrize("scale,shift", [(1.0e4, 0.0), (1.0e-3, 0.0), (1.0, 1.0e4), (1.0, -3.0e5), (37.0, 911.0)])
+def test_octree_on_scaled_and_shifted_scenes(backend, pkg, oracle, scene_of, scale, shift):
+    """The 2000-triangle scene blown up, shrunk and moved far from the origin (where an ulp of a coordinate is no longer small against
+    the cells, and the builder's padding has to grow with it): octree hits - host- and device-built - equal the brute force, for rays
+    from inside the scene, from far outside it, along the axes and in the octree's split planes."""
+    from mcrt_amd import scenes
+
+    f32 = np.float32
+    flat = scenes.transformed(scene_of("config4_2k"), scale, shift)
+    sc = oracle.scene(flat)
+    rng = np.random.default_rng(77)
+    n = 6000
+    inside = (rng.uniform(-4.5, 4.5, (n, 3)) * scale + shift).astype(f32)
+    outside = (rng.normal(size=(n, 3)) * 40.0 * scale + shift).astype(f32)
+    d_in = rng.normal(size=(n, 3)).astype(f32)
+    d_out = ((rng.uniform(-4.5, 4.5, (n, 3)) * scale + shift) - outside).astype(f32)
+    axis = np.zeros((n, 3), f32)
+    axis[np.arange(n), rng.integers(0, 3, n)] = rng.choice([-1.0, 1.0], n)
+    planes = inside.copy()
+    planes[np.arange(n), rng.integers(0, 3, n)] = f32(shift) + f32(scale) * rng.choice([-2.5, 0.0, 1.25, 2.5], n).astype(f32)
+    o = np.concatenate([inside, outside, inside, planes])
+    d = np.concatenate([d_in, d_out, axis, np.where(rng.random((n, 1)) < 0.5, axis, d_in)]).astype(f32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o, d = np.ascontiguousarray(o, f32), np.ascontiguousarray(d, f32)
+    want = oracle.intersect(sc, o, d)
+    assert (want[0] >= 0).mean() > 0.3
+    for device_build in (False, True):
+        backend.upload_scene(flat, device_build=device_build)
+        for mode in (pkg.ACCEL_OCTREE, pkg.ACCEL_BRUTE):
+            backend.set_accel(mode)
+            obj, elem, t = backend.intersect(o, d)
+            bad = np.flatnonzero((obj != want[0]) | (elem != want[1]) | (t.view(np.uint32) != want[2].view(np.uint32)))
+            assert len(bad) == 0, (device_build, mode, len(bad), bad[:5], o[bad[:2]], d[bad[:2]], obj[bad[:2]], want[0][bad[:2]])
+    backend.set_accel(pkg.ACCEL_AUTO)
+    backend.upload_scene(scene_of("cornell"))

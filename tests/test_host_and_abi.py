@@ -235,6 +235,29 @@ def test_more_objects_than_the_gate_cache_holds(pkg, oracle, po, scene_of):
         assert np.array_equal(g, w)
 
 
+@pytest.mark.parametrize("scale,shift", [(1.0e4, 0.0), (1.0e-3, 0.0), (1.0, 1.0e4), (1.0, -3.0e5)])
+def test_octree_replay_on_scaled_and_shifted_scenes(pkg, oracle, scene_of, scale, shift):
+    """The walk's padding argument where an ulp of a coordinate is no longer small against the cells: the CPU replay of the octree walk
+    equals the brute force on the 2000-triangle scene blown up, shrunk and moved far from the origin."""
+    from mcrt_amd import scenes
+
+    flat = scenes.transformed(scene_of("config4_2k"), scale, shift)
+    sc = oracle.scene(flat)
+    rng = np.random.default_rng(78)
+    n = 3000
+    o = np.concatenate([rng.uniform(-4.5, 4.5, (n, 3)) * scale + shift, rng.normal(size=(n, 3)) * 40.0 * scale + shift]).astype(np.float32)
+    d = rng.normal(size=(2 * n, 3)).astype(np.float32)
+    d[n:] = ((rng.uniform(-4.5, 4.5, (n, 3)) * scale + shift) - o[n:]).astype(np.float32)
+    d[::7, 0] = 0.0
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o, d = np.ascontiguousarray(o), np.ascontiguousarray(d.astype(np.float32))
+    want = oracle.intersect(sc, o, d)
+    info, box, words, refs = pkg.build_scene_image(flat)
+    got = oracle.intersect_octree(sc, info, box, words, refs, o, d)
+    for g, w in zip(got, want):
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_octree_structure_invariants(pkg, scene_of, name):
     flat = scene_of(name)
