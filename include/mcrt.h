@@ -202,7 +202,12 @@ int mcrt_camera_rays(mcrt_ctx* ctx, uint64_t n, const float* xs, const float* ys
 /* Scene::IntersectRay, source/scene.cpp:62-80, for n rays (host buffers,
  * n*3 floats each).  out_obj = object index or -1 on a miss, out_elem =
  * RayIntersectionInfo::elementIndex, out_t = hitDistance (FLT_MAX on a miss),
- * source/core/ray.h:17-29. */
+ * source/core/ray.h:17-29.  Directions are unit vectors, as every ray the
+ * reference builds is (camera.h:56, scene.cpp:11-30); zero, NaN and infinite
+ * components answer as the reference's arithmetic does.  A direction of another
+ * length is outside the contract: SphereObject::Intersects (sphere.h:16-52)
+ * then reports distances that are not along the ray, which only MCRT_ACCEL_BRUTE
+ * reproduces. */
 int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const float* origins, const float* dirs,
                    int32_t* out_obj, uint32_t* out_elem, float* out_t);
 

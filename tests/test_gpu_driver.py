@@ -630,3 +630,36 @@ def test_octree_on_scaled_and_shifted_scenes(backend, pkg, oracle, scene_of, sca
             assert len(bad) == 0, (device_build, mode, len(bad), bad[:5], o[bad[:2]], d[bad[:2]], obj[bad[:2]], want[0][bad[:2]])
     backend.set_accel(pkg.ACCEL_AUTO)
     backend.upload_scene(scene_of("cornell"))
+
+
+@pytest.mark.parametrize("name", ["cornell", "config4_2k"])
+def test_degenerate_rays(backend, pkg, oracle, scene_of, name):
+    """Rays a caller should not send but can: zero direction, exact-zero and denormal-range components, NaN and infinite components,
+    origins far away.  Every mode returns what the brute force of scene.cpp:62-80 returns for them (the oracle runs the reference's arithmetic,
+    NaN comparisons included), and nothing hangs."""
+    flat = scene_of(name)
+    sc = oracle.scene(flat)
+    rng = np.random.default_rng(9)
+    n = 512
+    o = rng.uniform(-4.0, 4.0, (8 * n, 3)).astype(np.float32)
+    d = rng.normal(size=(8 * n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)              # unit directions are the contract (include/mcrt.h), as every ray of the reference
+    d[0 * n:1 * n] = 0.0                                        # no direction at all
+    d[1 * n:2 * n, 0] = 0.0; d[1 * n:2 * n, 1] = 0.0; d[1 * n:2 * n, 2] = np.sign(d[1 * n:2 * n, 2])     # along an axis, two exact zeros
+    d[2 * n:3 * n, 1] = np.float32(1e-38)                       # a denormal-range component
+    d[2 * n:3 * n] /= np.linalg.norm(d[2 * n:3 * n], axis=1, keepdims=True)
+    d[3 * n:4 * n, 0] = np.nan
+    d[4 * n:5 * n, 1] = np.inf
+    o[5 * n:6 * n, 2] = np.nan
+    o[6 * n:7 * n] *= np.float32(1e30)
+    o[7 * n:8 * n, 0] = -np.inf
+    want = oracle.intersect(sc, o, d)
+    backend.upload_scene(flat)
+    for mode in (pkg.ACCEL_BRUTE, pkg.ACCEL_OCTREE, pkg.ACCEL_AUTO, pkg.ACCEL_SCAN):
+        backend.set_accel(mode)
+        obj, elem, t = backend.intersect(o, d)
+        hit = want[0] >= 0
+        assert np.array_equal(obj, want[0]), (mode, np.flatnonzero(obj != want[0])[:8])
+        assert np.array_equal(elem[hit], want[1][hit]) and np.array_equal(t[hit].view(np.uint32), want[2][hit].view(np.uint32)), mode
+    backend.set_accel(pkg.ACCEL_AUTO)
+    backend.upload_scene(scene_of("cornell"))
