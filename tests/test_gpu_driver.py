@@ -323,6 +323,27 @@ def test_device_built_octree_is_the_host_built_one(backend, pkg, oracle, po, sce
         assert np.array_equal(wobj, g["obj"][:5000]) and np.array_equal(welem, g["elem"][:5000]) and np.array_equal(wt, g["t"][:5000])
 
 
+@pytest.mark.parametrize("case", ["shifted", "shrunk", "random3", "random11", "many_objects"])
+def test_device_built_octree_equals_host_built_on_more_scenes(backend, pkg, scene_of, case):
+    """Tree equality (boxes, child words, lists as sets) away from the fixtures: a scene far from the origin (the node arrays grow
+    during the build), a tiny one, random populations, 131 objects."""
+    from mcrt_amd import scenes
+
+    flat = {"shifted": lambda: scenes.transformed(scene_of("config4_2k"), 1.0, 1.0e4), "shrunk": lambda: scenes.transformed(scene_of("config4_2k"), 1.0e-3, 0.0),
+            "random3": lambda: scenes.random_scene(scene_of("cornell"), 3), "random11": lambda: scenes.random_scene(scene_of("cornell"), 11),
+            "many_objects": lambda: scenes.many_objects(scene_of("cornell"))}[case]()
+    for accel in (None, pkg.AccelParams(2, 9, 0.0)):
+        hinfo, hbox, hwords, hrefs = pkg.build_scene_image(flat, accel)
+        backend.upload_scene(flat, accel, device_build=True)
+        info = backend.octree_info()
+        assert (info.node_count, info.prim_ref_count, info.max_depth, info.pad) == (hinfo.node_count, hinfo.prim_ref_count, hinfo.max_depth, hinfo.pad)
+        box, words, refs = backend.octree_download()
+        assert np.array_equal(box.view(np.uint32), hbox.view(np.uint32))
+        assert np.array_equal(words[:, 0], hwords[:, 0])
+        assert _lists(words, refs) == _lists(hwords, hrefs)
+    backend.upload_scene(scene_of("cornell"))
+
+
 def test_device_rebuild_after_an_edit(backend, pkg, oracle, scene_of, golden):
     """A scene edited between frames (a box moved, the 2000-triangle mesh sheared): re-indexed on the device, every query answers
     as the brute force over the EDITED scene does, and a render through it equals the render through a host-built tree."""
