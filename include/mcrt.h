@@ -158,7 +158,10 @@ int mcrt_set_stream(mcrt_ctx* ctx, void* hip_stream);
  * source/accelerationstructures/octree.h:77-92 is rebuilt here as a flat,
  * per-primitive structure of node and leaf records).  `accel` may be NULL.
  * Limits (MCRT_ERR_LIMIT): at most 512 objects, and their table has to fit the
- * LDS budget; octree depth <= 256, fewer than 2^24 nodes. */
+ * LDS budget; fewer than 2^24 octree nodes.  accel->max_depth above
+ * MCRT_MAX_TREE_DEPTH (12) is clamped to it, not refused: deeper levels only
+ * split cells that are already smaller than 1/4096 of the scene. */
+#define MCRT_MAX_TREE_DEPTH 12
 int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* scene,
                       const mcrt_accel_params* accel);
 
@@ -170,7 +173,8 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* scene,
  * passes the whole edited scene again and kernels re-index it level by level (same
  * cells, split rule, overlap tests and node numbering as the host build, so every
  * query answers as before: the brute force of source/scene.cpp:62-80).
- * mcrt_last_build_ms: device time of the last such build. */
+ * mcrt_last_build_ms: device time of that build, for the scene in use
+ * (MCRT_ERR_STATE when the scene in use was built on the host, or none is). */
 int mcrt_upload_scene_device_build(mcrt_ctx* ctx, const mcrt_scene_desc* scene,
                                    const mcrt_accel_params* accel);
 int mcrt_last_build_ms(mcrt_ctx* ctx, float* out_ms);
@@ -207,7 +211,14 @@ int mcrt_camera_rays(mcrt_ctx* ctx, uint64_t n, const float* xs, const float* ys
  * components answer as the reference's arithmetic does.  A direction of another
  * length is outside the contract: SphereObject::Intersects (sphere.h:16-52)
  * then reports distances that are not along the ray, which only MCRT_ACCEL_BRUTE
- * reproduces. */
+ * reproduces.
+ * Origins may lie anywhere.  MCRT_ACCEL_OCTREE answers a ray whose origin has a
+ * coordinate beyond mcrt_octree_info.far_origin_limit (= pad / (32 * FLT_EPSILON),
+ * about 26 scene sizes from the coordinate origin with the default padding) - or
+ * not a number - with the reference's loop over all objects instead of the tree:
+ * out there one ulp of the origin's coordinate is no longer small against the
+ * padding of the tree, and the reference's own arithmetic decides inside that
+ * noise.  Same results, O(primitives) per such ray. */
 int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const float* origins, const float* dirs,
                    int32_t* out_obj, uint32_t* out_elem, float* out_t);
 
@@ -291,8 +302,11 @@ int mcrt_accumulator(mcrt_ctx* ctx, double** out_d_accum);
  * mcrt_reduce: ncclReduce(sum, ncclDouble, width*height*3) of the accumulator
  * in use into rank `root`, in place, on the context's stream (asynchronous).
  * `comm` is an ncclComm_t (RCCL); every rank of the communicator calls it, each
- * from its own thread or process.  RCCL is bound at run time: without librccl
- * the call fails with MCRT_ERR_NO_DEVICE and nothing else is affected.
+ * from its own thread or process.  RCCL is bound at run time (symbols already
+ * in the process, else librccl.so.1 / librccl.so, or the library named by the
+ * environment variable MCRT_RCCL_LIB): without a loadable librccl that reports
+ * an NCCL 2.x API these three calls fail with MCRT_ERR_NO_DEVICE and a message,
+ * and nothing else is affected.
  * mcrt_comm_init_all / mcrt_comm_destroy: ncclCommInitAll / ncclCommDestroy for
  * the one-process-many-GPUs case (out_comms: n ncclComm_t, rank i on
  * devices[i]), so that a C caller needs no RCCL headers.  A process that
@@ -366,7 +380,9 @@ typedef struct mcrt_octree_info {
     uint32_t lds_resident;     /* 1 when kernels stage the whole image in LDS */
     float root_cell_min[3];    /* the root's cell: every node's cell follows from it by halving  */
     float root_cell_max[3];    /* at the centre, centre = min + 0.5f * (max - min), octant bit a */
-    float pad;                 /* set = upper half on axis a; cells are entered with this padding */
+    float pad;                 /* set = upper half on axis a.  pad: the builder's padding of cells and */
+                               /* boxes; the walk routes rays with HALF of it (margin for its own rounding) */
+    float far_origin_limit;    /* see mcrt_intersect */
 } mcrt_octree_info;
 
 int mcrt_octree_info_get(mcrt_ctx* ctx, mcrt_octree_info* out);

@@ -93,6 +93,7 @@ class OctreeInfo(C.Structure):
         ("root_cell_min", C.c_float * 3),
         ("root_cell_max", C.c_float * 3),
         ("pad", C.c_float),
+        ("far_origin_limit", C.c_float),
     ]
 
 

@@ -492,7 +492,7 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
             }
             if constexpr (kWalk) {
                 // a lane without a ray has an empty stack: it sits in the walk loop as a finished lane
-                if (live && !walking) { walk.begin(sm, v, walk_stack, ln.ro, ln.rd, cn); walking = true; }
+                if (live && !walking) { walk.begin(sm, big, v, walk_stack, ln.ro, ln.rd, cn); walking = true; }
                 walk.run(sm, big, v, walk_stack, ln.ro, ln.rd, cn, policy.refill);
                 if (!live || !walk.done()) continue;          // no ray, or still in mid-traversal: nothing to shade yet
                 walking = false;
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(kBlock, kBlocksPerCu) void k_wf_trace(const WfArgs 
                 o = mk(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z));
                 d = mk(__uint_as_float(c1.x), __uint_as_float(c1.y), __uint_as_float(c1.z));
                 OctreeWalk<LdsPtr, GlbPtr, kCount>::ray_setup(v, d, inv, padt, dts, flip);
-                walk.begin(sm, v, st, o, d, cn);
+                walk.begin(sm, big, v, st, o, d, cn);
             }
             const uint32_t taken = (uint32_t)__popcll(need) < avail ? (uint32_t)__popcll(need) : avail;
             w_pos += taken;
@@ -1417,35 +1417,53 @@ int need_scene(mcrt_ctx* c, bool camera)
 
 // RCCL is bound at run time (dlopen), so that the library loads - and every single-GPU entry point works - where librccl is
 // absent, and a process that already carries an RCCL (PyTorch ships its own) is not given a second one: symbols already in
-// the process are preferred.  Enum values are those of rccl.h (ncclDouble = 8, ncclSum = 0).
+// the process are preferred.  MCRT_RCCL_LIB names the library to load instead of librccl.so.1 / librccl.so.  The two enum values
+// mcrt_reduce passes are those of rccl.h for every NCCL 2.x API (ncclDouble = 8, ncclSum = 0): the major version is checked once
+// through ncclGetVersion, and a library that reports anything else is refused rather than trusted.
 struct Rccl {
     typedef int (*InitAll)(void** comms, int ndev, const int* devlist);
     typedef int (*Destroy)(void* comm);
     typedef int (*Reduce)(const void* send, void* recv, size_t count, int dtype, int op, int root, void* comm, hipStream_t stream);
     typedef const char* (*ErrStr)(int);
+    typedef int (*GetVersion)(int*);
     InitAll init_all = nullptr;
     Destroy destroy = nullptr;
     Reduce reduce = nullptr;
     ErrStr err = nullptr;
+    int version = 0;
     std::string why;
     bool ok = false;
 };
+constexpr int kNcclDouble = 8, kNcclSum = 0;       // rccl.h: ncclDataType_t::ncclDouble (= ncclFloat64), ncclRedOp_t::ncclSum
 const Rccl& rccl()
 {
     static const Rccl r = [] {
         Rccl x;
         void* h = RTLD_DEFAULT;
         if (!dlsym(RTLD_DEFAULT, "ncclReduce")) {
-            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-            if (!h) { x.why = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?"); return x; }
+            const char* named = getenv("MCRT_RCCL_LIB");
+            if (named && *named) h = dlopen(named, RTLD_NOW | RTLD_GLOBAL);
+            else {
+                h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+                if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            }
+            if (!h) {
+                const char* m = dlerror();               // once: the call clears the message
+                x.why = std::string("librccl not loadable: ") + (m ? m : "?");
+                return x;
+            }
         }
         x.init_all = (Rccl::InitAll)dlsym(h, "ncclCommInitAll");
         x.destroy = (Rccl::Destroy)dlsym(h, "ncclCommDestroy");
         x.reduce = (Rccl::Reduce)dlsym(h, "ncclReduce");
         x.err = (Rccl::ErrStr)dlsym(h, "ncclGetErrorString");
-        x.ok = x.init_all && x.destroy && x.reduce;
-        if (!x.ok) x.why = "librccl lacks ncclCommInitAll / ncclCommDestroy / ncclReduce";
+        if (!(x.init_all && x.destroy && x.reduce)) { x.why = "librccl lacks ncclCommInitAll / ncclCommDestroy / ncclReduce"; return x; }
+        // NCCL_VERSION_CODE: major * 1000 + ... up to 2.8, major * 10000 + ... from 2.9 on
+        Rccl::GetVersion ver = (Rccl::GetVersion)dlsym(h, "ncclGetVersion");
+        if (!ver || ver(&x.version) != 0) { x.why = "librccl: ncclGetVersion missing or failing, enum values cannot be checked"; return x; }
+        const int major = x.version >= 20000 ? x.version / 10000 : x.version / 1000;
+        if (major != 2) { x.why = "librccl reports NCCL API version " + std::to_string(x.version) + ": ncclDouble / ncclSum are known for 2.x only"; return x; }
+        x.ok = true;
         return x;
     }();
     return r;
@@ -1568,6 +1586,7 @@ int upload_scene_impl(mcrt_ctx* c, const mcrt_scene_desc* scene, const mcrt_acce
     HIP_TRY(c, hipMalloc(&c->d_small, std::max<size_t>(flat.small_img.size(), 1) * 4));
     HIP_TRY(c, hipMemcpy(c->d_small, flat.small_img.data(), flat.small_img.size() * 4, hipMemcpyHostToDevice));
     if (!device_build) {
+        c->last_build_ms = 0.0f;                 // mcrt_last_build_ms reports the device build of the scene IN USE only
         HIP_TRY(c, hipMalloc(&c->d_big, std::max<size_t>(flat.big_img.size(), 1) * 4));
         HIP_TRY(c, hipMemcpy(c->d_big, flat.big_img.data(), flat.big_img.size() * 4, hipMemcpyHostToDevice));
         c->tree_on_host = true;
@@ -1576,6 +1595,7 @@ int upload_scene_impl(mcrt_ctx* c, const mcrt_scene_desc* scene, const mcrt_acce
         // the host flattener has laid out the triangle and pair records from word 0 of its big image
         bld::Params P = { flat.view.nobj, flat.view.nprim, flat.view.ntri, flat.max_leaf, flat.max_depth, flat.stay, flat.pad_rel };
         bld::Result R;
+        c->last_build_ms = 0.0f;
         if (bld::build_on_device(c->stream, P, c->d_small, flat.view.off_obj, scene->triangle_count ? &scene->triangles[0].v0[0] : nullptr, flat.big_img,
                                  flat.view.off_pair, R, err)) {
             if (R.d_big) (void)hipFree(R.d_big);
@@ -1586,7 +1606,8 @@ int upload_scene_impl(mcrt_ctx* c, const mcrt_scene_desc* scene, const mcrt_acce
         v.nnode = R.nnode; v.off_node = R.off_node; v.off_leaf = R.off_leaf; v.off_tri = R.off_tri; v.tri_src = R.off_tri; v.off_pair = R.off_pair;
         v.big_words = (uint32_t)R.big_words;
         for (int a = 0; a < 3; ++a) v.root_size[a] = R.root_cell[3 + a] - R.root_cell[a];
-        v.walk_pad = R.pad;
+        v.walk_pad = kWalkPadFraction * R.pad;
+        v.far_limit = R.pad * kFarOriginFactor;
         flat.tree_depth = R.depth; flat.ref_count = R.nrefs; flat.pad = R.pad;
         for (int a = 0; a < 6; ++a) flat.root_cell[a] = R.root_cell[a];
         flat.big_img.clear(); flat.big_img.shrink_to_fit();
@@ -1999,7 +2020,7 @@ int mcrt_reduce(mcrt_ctx* c, void* comm, int root)
     int rc = bind_device(c);
     if (rc) return rc;
     // one collective per pass: the W*H*3 doubles of every rank summed into `root`, in place, on the context's stream
-    const int e = r.reduce(c->d_accum, c->d_accum, c->accum_pixels * 3, /*ncclDouble*/ 8, /*ncclSum*/ 0, root, comm, c->stream);
+    const int e = r.reduce(c->d_accum, c->d_accum, c->accum_pixels * 3, kNcclDouble, kNcclSum, root, comm, c->stream);
     if (e != 0) return fail(c, MCRT_ERR_HIP, std::string("ncclReduce: ") + (r.err ? r.err(e) : "error"));
     return MCRT_OK;
 }
@@ -2109,6 +2130,7 @@ int mcrt_octree_info_get(mcrt_ctx* c, mcrt_octree_info* out)
     out->lds_resident = c->big_in_lds ? 1u : 0u;
     for (int a = 0; a < 3; ++a) { out->root_cell_min[a] = c->flat.root_cell[a]; out->root_cell_max[a] = c->flat.root_cell[3 + a]; }
     out->pad = c->flat.pad;
+    out->far_origin_limit = c->view.far_limit;
     return MCRT_OK;
 }
 
@@ -2156,6 +2178,7 @@ int mcrt_scene_image_info(const mcrt_scene_image* image, mcrt_octree_info* out)
     out->lds_resident = (small_bytes + (size_t)f.view.big_words * 4 <= kLdsBudgetBytes) ? 1u : 0u;
     for (int a = 0; a < 3; ++a) { out->root_cell_min[a] = f.root_cell[a]; out->root_cell_max[a] = f.root_cell[3 + a]; }
     out->pad = f.pad;
+    out->far_origin_limit = f.view.far_limit;
     return MCRT_OK;
 }
 

@@ -394,8 +394,12 @@ inline uint32_t blocks_for(uint64_t n) { return (uint32_t)std::max<uint64_t>(1, 
 inline int build_on_device(hipStream_t stream, const Params& P, const uint32_t* d_small, uint32_t off_obj, const float* h_raw_tris, const std::vector<uint32_t>& tail,
                            uint32_t tail_off_pair, Result& R, std::string& err)
 {
-    hipEvent_t ev0, ev1;
-    BLD_TRY(hipEventCreate(&ev0)); BLD_TRY(hipEventCreate(&ev1));
+    struct Events {                     // destroyed on every way out (BLD_TRY returns early)
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } events;
+    BLD_TRY(hipEventCreate(&events.a)); BLD_TRY(hipEventCreate(&events.b));
+    const hipEvent_t ev0 = events.a, ev1 = events.b;
     Buf<float> raw, pbox, rootinfo;
     Buf<uint32_t> prim_obj, counter;
     Buf<uint8_t> skip;
@@ -532,7 +536,6 @@ inline int build_on_device(hipStream_t stream, const Params& P, const uint32_t* 
     BLD_TRY(hipEventRecord(ev1, stream));
     BLD_TRY(hipStreamSynchronize(stream));
     BLD_TRY(hipEventElapsedTime(&R.build_ms, ev0, ev1));
-    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
     for (int a = 0; a < 6; ++a) R.root_cell[a] = rootinfo_h[a];
     R.pad = pad;
     return 0;

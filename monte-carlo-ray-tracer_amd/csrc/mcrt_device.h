@@ -561,11 +561,20 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
     // instead of on first contact: evaluated lazily, about one lane of the wavefront meets a new mesh in every step, and the whole
     // wavefront sits through the six IEEE divisions of the gate for it (measured on the 5-object 1M-triangle scene: 15 % of a step).
     static constexpr uint32_t kEagerGates = 8;
-    template <class St> MCRT_DEV void begin(PS sm, const SceneView& v, St& st, V3 o, V3 d, Counters& cn)
+    template <class St> MCRT_DEV void begin(PS sm, PB big, const SceneView& v, St& st, V3 o, V3 d, Counters& cn)
     {
+        gate_known = 0; gate_pass = 0;
+        // An origin far outside the scene (or NaN): an ulp of its coordinate is no longer small against the padding the walk decides
+        // with, and the reference's own arithmetic decides inside that noise.  Such a ray is answered by the reference's loop over all
+        // objects, right here; the lane comes out finished.  (SceneView::far_limit; rays that start inside the scene - every bounce
+        // and shadow ray, any camera within ~26 scene sizes - never take this branch.)
+        if (!(fabsf(o.x) <= v.far_limit && fabsf(o.y) <= v.far_limit && fabsf(o.z) <= v.far_limit)) {
+            best = cast_brute<PS, PB, kCount>(sm, big, v, o, d, cn);
+            sp = 0; pleaf = NO_REFS;
+            return;
+        }
         best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax;
         if (kCount) cn.rays++;
-        gate_known = 0; gate_pass = 0;
         if (v.nobj <= kEagerGates) {
             for (uint32_t i = 0; i < v.nobj; ++i) {
                 const uint32_t orec = v.off_obj + i * OBJ_STRIDE;
@@ -643,7 +652,11 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
                 // the padding of [tb0, tb1], and the octant beyond it is entered the padding early.  A hit point always lies in the padded
                 // cell of the octant that is current at its distance (per axis it is on the same side of the mid plane or within the
                 // padding of it), and the builder references a primitive from every child whose padded cell it overlaps - so the
-                // primitive is met there, and the entry distance is not behind it (ties included).  The octant test this replaces
+                // primitive is met there, and the entry distance is not behind it (ties included).  "The padding" of these decisions
+                // (padt) is HALF the builder's: the distances below carry a rounding error of a few ulps of max(|origin|, |cell|), and
+                // with the builder's full padding a slow ray that runs 2e-7 OUTSIDE the padded neighbour cell was routed through that
+                // neighbour - which does not reference the primitive - for the rest of its way (round 2's hole; tests: pad_margin_rays).
+                // With half of it the walk's "within reach of the child" is always inside the builder's.  The octant test this replaces
                 // worked out all eight padded boxes (max3 / min3 / compare each) and pushed in a loop: ~225 instructions, now ~90.
                 const float cmn[3] = { __uint_as_float(rc.x), __uint_as_float(rc.y), __uint_as_float(rc.z) };
                 const float oo[3] = { o.x, o.y, o.z }, ii[3] = { inv.x, inv.y, inv.z }, pp[3] = { padt.x, padt.y, padt.z }, dd[3] = { dts.x, dts.y, dts.z };
@@ -763,7 +776,7 @@ MCRT_DEV Hit cast_octree(PS sm, PB big, const SceneView& v, V3 o, V3 d, Counters
 {
     OctreeWalk<PS, PB, kCount> w;
     ScratchStack st;
-    w.begin(sm, v, st, o, d, cn);
+    w.begin(sm, big, v, st, o, d, cn);
     w.run(sm, big, v, st, o, d, cn, 0u);
     return w.best;
 }

@@ -402,7 +402,8 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
     v = SceneView{};
     v.nobj = nobj; v.nlights = uint32_t(lights.size()); v.ntri = sc->triangle_count; v.nprim = nprim; v.nnode = nnode;
     for (int a = 0; a < 3; ++a) v.root_size[a] = root_cell_v[3 + a] - root_cell_v[a];
-    v.walk_pad = pad;
+    v.walk_pad = kWalkPadFraction * pad;
+    v.far_limit = pad * kFarOriginFactor;
     v.off_obj = 0;
     v.off_lights = v.off_obj + nobj * OBJ_STRIDE;
     v.off_bg = (v.off_lights + v.nlights + 1u) & ~1u;   // doubles: even word offset

@@ -4,7 +4,7 @@
 //   SMALL: per-object records (geometry header, mesh gate box, light vectors,
 //          material), the light list and the background colour.  A few KB at
 //          most; every kernel stages it in LDS.
-//   BIG:   the flat octree (32-byte node records + per-node lists of 48-byte
+//   BIG:   the flat octree (48-byte node records + per-node lists of 48-byte
 //          leaf records that carry the triangle they refer to), the triangle
 //          records and the triangle-pair records of the scan path.
 //          Staged in LDS when SMALL+BIG fit the LDS budget (all Cornell-box
@@ -85,6 +85,13 @@ constexpr uint32_t NO_REFS = 0xFFFFFFFFu;
 constexpr uint32_t REF_LAST = 0x80000000u;   // set on the last reference of a node's list
 constexpr uint32_t MISS = 0xFFFFFFFFu;
 
+// The walk's margins against its own rounding.  The builder pads cells and boxes by `pad` (mcrt_flatten.cpp); the walk routes a ray
+// with walk_pad = kWalkPadFraction * pad, which leaves pad / 2 between "the walk treats the ray as within reach of a child" and "the
+// builder referenced the primitive from that child".  The walk's plane and slab distances are off by a few ulps of max(|origin|,
+// |cell|) in position units; pad >= 256 ulps of the largest scene coordinate, so the margin holds while the origin is within
+// far_limit = pad * kFarOriginFactor = pad / (32 * FLT_EPSILON), i.e. while 16 ulps of the origin's coordinate stay below pad / 2.
+constexpr float kWalkPadFraction = 0.5f;
+constexpr float kFarOriginFactor = 262144.0f;      // 2^18 = 1 / (32 * FLT_EPSILON)
 constexpr uint32_t MAX_TREE_DEPTH = 12;
 constexpr uint32_t TRAVERSAL_STACK = 7 * MAX_TREE_DEPTH + 4;
 constexpr uint32_t MAX_OBJECTS_GATED = 64;   // the per-ray mesh-gate cache is a 64-bit mask: objects 0..63 are cached, later ones evaluated on every contact
@@ -101,7 +108,11 @@ struct SceneView {
     uint32_t tri_src;            // word offset of the triangle records in the global BIG image (== off_tri except in the
                                  // view handed to the flat-scan kernels, whose off_tri addresses their LDS copy)
     float root_size[3];          // extent of the root cell (a node's cell size = root_size * its NODE_SCALE)
-    float walk_pad;              // the builder's padding: octants are entered through cells widened by this much
+    float walk_pad;              // HALF the builder's padding: the walk decides "within the padding of a mid plane" with this, so that
+                                 // its own rounding (about an ulp of the origin's coordinate) can never put a ray into a child the
+                                 // builder did not reference the primitive from (kWalkPadFraction, OctreeWalk::visit)
+    float far_limit;             // origins with a coordinate beyond this (or NaN) are answered by the loop over all objects: there an
+                                 // ulp of the coordinate is no longer small against walk_pad (kFarOriginFactor, OctreeWalk::begin)
 };
 
 } // namespace mcrt

@@ -29,6 +29,7 @@
 // --checkpoint FILE rewrites FILE after every pass (header: magic, width, height, samples done, seed; then the
 // W*H*3 accumulator doubles); --resume FILE continues such a render: samples [done, spp) are rendered on top of
 // the stored sums.  The reference has nothing comparable (its accumulators live and die with the process).
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -217,7 +218,7 @@ int main(int argc, char** argv)
     }
 
     std::vector<uint8_t> image;
-    uint64_t samplesTraced = 0;
+    uint64_t samplesTraced = 0, droppedTotal = 0;
     const auto t0 = std::chrono::steady_clock::now();
     if (unlit) {
         // RAY_TRACE_UNLIT, main.cpp:39,124-135
@@ -275,6 +276,8 @@ int main(int argc, char** argv)
         // One worker per device.  Rank 0 (the first device) holds the job's sums, resolves and checkpoints.
         Barrier barrier(nDev);
         std::vector<int> failed(nDev, 0);
+        std::atomic<bool> anyFailed{ false };        // a rank whose pass failed: EVERY rank leaves before the collective, or all ranks would wait for it forever
+        std::vector<uint64_t> droppedCleared(nDev, 0);   // non-finite samples a rank counted before its per-pass Clear zeroed the counter
         auto worker = [&](unsigned r) {
             Scene& sc = *scenes[r];
             Camera& cam = *cameras[r];
@@ -287,21 +290,30 @@ int main(int argc, char** argv)
                 // a rank with no sample in this window still binds its camera (the reduce needs its zeroed accumulator)
                 ok = ok && sc.Render(cam, begin, mine, depth, seed);
                 if (nDev > 1) {
-                    if (distinct) ok = ok && sc.Reduce(cam, comms[r], 0);
+                    // every rank issues the reduction of this pass, or none does
+                    if (!distinct) ok = ok && mcrt_synchronize(sc.Context()) == MCRT_OK;
+                    if (!ok) anyFailed.store(true);
+                    barrier.Wait();                                              // every rank's pass is enqueued (same GPU: complete) and its verdict known
+                    if (anyFailed.load()) { ok = false; break; }
+                    if (distinct) ok = sc.Reduce(cam, comms[r], 0);
                     else {
-                        ok = ok && mcrt_synchronize(sc.Context()) == MCRT_OK;
-                        barrier.Wait();                                          // every context's pass is complete
                         if (r == 0) for (unsigned j = 1; j < nDev && ok; ++j) ok = sc.AddAccumulatorOf(cam, *scenes[j]);
                         if (r == 0) ok = ok && mcrt_synchronize(sc.Context()) == MCRT_OK;
                         barrier.Wait();                                          // rank 0 has read the others' sums
                     }
-                    if (r != 0) ok = ok && sc.Clear(cam);                        // their sums now live on rank 0
+                    if (r != 0 && ok) {
+                        uint64_t d = 0;                                          // Clear zeroes the dropped-sample counter with the sums
+                        if (mcrt_dropped_samples(sc.Context(), &d) == MCRT_OK) droppedCleared[r] += d;
+                        ok = sc.Clear(cam);                                      // their sums now live on rank 0
+                    }
                 }
                 if (r == 0) {
                     sc.SetSampleCount(cam, done + n);
                     ok = ok && sc.Resolve(cam, tonemap, gamma, exposure, image);      // what the window would show after this pass
                     if (ok && !checkpoint.empty() && !WriteCheckpoint(checkpoint, sc, cam, done + n, seed)) { std::fprintf(stderr, "cannot write %s\n", checkpoint.c_str()); ok = false; }
                 }
+                if (!ok && nDev == 1) break;
+                // (nDev > 1: a failure after the reduction is reported at the barrier of the next pass, where all ranks leave together)
             }
             failed[r] = ok ? 0 : 1;
         };
@@ -309,14 +321,14 @@ int main(int argc, char** argv)
         for (unsigned r = 1; r < nDev; ++r) threads.emplace_back(worker, r);
         worker(0);
         for (std::thread& t : threads) t.join();
-        for (unsigned r = 0; r < nDev; ++r) if (failed[r]) { std::fprintf(stderr, "render failed on device %d\n", devices[r]); return 1; }
+        for (unsigned r = 0; r < nDev; ++r) if (failed[r]) { std::fprintf(stderr, "render failed on device %d: %s\n", devices[r], mcrt_last_error(scenes[r]->Context())); return 1; }
+        for (unsigned r = 0; r < nDev; ++r) droppedTotal += droppedCleared[r];
         if (first >= spp && !scene->Resolve(camera, tonemap, gamma, exposure, image)) return 1;
         samplesTraced = uint64_t(width) * height * (spp - std::min(first, spp));
     }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("Render finished at %.3f s: %ux%u, %u spp, %u device(s), %.1f Msamples/s\r\n", secs, width, height, randomPixels ? 0u : spp, nDev,
                 double(samplesTraced) / secs / 1e6);
-    uint64_t droppedTotal = 0;
     for (auto& sc : scenes) { uint64_t d = 0; if (mcrt_dropped_samples(sc->Context(), &d) == MCRT_OK) droppedTotal += d; }
     if (droppedTotal) std::printf("%llu non-finite samples dropped\r\n", (unsigned long long)droppedTotal);
     const bool png = out.size() >= 4 && out.compare(out.size() - 4, 4, ".png") == 0;

@@ -39,7 +39,7 @@ def unit(v):
     return (v / n[:, None]).astype(F)
 
 
-def split_planes(flat, levels=3):
+def split_planes(flat, levels=3, pad=None):
     """Per axis, the octree split planes of the first `levels` levels exactly as mcrt_flatten.cpp computes them in
     float32 (root cell = union of the primitive boxes grown by 2 * pad; centre = mn + 0.5f * (mx - mn), recursively).
     The replicated padding is checked against the built tree: the root's stored box is the primitive union +- pad."""
@@ -53,9 +53,10 @@ def split_planes(flat, levels=3):
             lo = np.minimum(lo, (o["position"] - r).astype(F)); hi = np.maximum(hi, (o["position"] + r).astype(F))
     extent = F((hi - lo).max())
     mag = F(max(np.abs(lo).max(), np.abs(hi).max()))
-    pad = max(F(1.0e-4) * max(extent, F(1.0e-3)), F(256.0) * np.finfo(F).eps * mag)
-    _, box, _, _ = pkg.build_scene_image(flat)
-    assert np.array_equal(box[0, :3], (lo - pad).astype(F)) and np.array_equal(box[0, 3:], (hi + pad).astype(F)), "pad rule out of step with mcrt_flatten.cpp"
+    if pad is None:
+        pad = max(F(1.0e-4) * max(extent, F(1.0e-3)), F(256.0) * np.finfo(F).eps * mag)
+        _, box, _, _ = pkg.build_scene_image(flat)
+        assert np.array_equal(box[0, :3], (lo - pad).astype(F)) and np.array_equal(box[0, 3:], (hi + pad).astype(F)), "pad rule out of step with mcrt_flatten.cpp"
     mn, mx = (lo - F(2.0) * pad).astype(F), (hi + F(2.0) * pad).astype(F)
     planes = []
     for a in range(3):
@@ -108,6 +109,77 @@ def split_plane_rays(R, cam, flat, rng, per_plane=48):
     co, cd = R.camera_rays(cam, xs, ys)
     os_.append(co); ds_.append(cd)
     return np.concatenate(os_).astype(F), np.concatenate(ds_).astype(F)
+
+
+def _ulp_step(x, k):
+    """x moved by k units in the last place (float32), k a small signed integer array."""
+    x = np.asarray(x, F).copy()
+    for step in range(1, 9):
+        up, dn = k >= step, k <= -step
+        x[up] = np.nextafter(x[up], F(np.inf)); x[dn] = np.nextafter(x[dn], F(-np.inf))
+    return x
+
+
+def pad_margin_rays(flat, rng, total=6000, levels=3, accel=None):
+    """Round 3: rays that run just inside / just outside the PADDING of a split plane.  The builder references a primitive from
+    every child whose cell it comes within `pad` of; the walk has to decide "within the padding of the plane" from float
+    arithmetic whose rounding (about an ulp of the origin's coordinate) is what separates the two sides here.  Origin coordinate
+    on axis a = plane + {0, +-pad/2, +-pad} moved by {0, +-1, +-2, +-8} ulps; direction component on that axis +-[1e-38, 1e-8]
+    (the ray stays in the margin for its whole length), the others O(1); a quarter of the rays with a second component exactly
+    +-0, a quarter with the origin in the margin of a second plane as well; and the two rays of VERDICT.md round 2."""
+    info, _, _, _ = pkg.build_scene_image(flat, accel)
+    pad = F(info.pad)
+    planes = split_planes(flat, levels, pad)
+    lo = np.array([p.min() for p in planes], F); hi = np.array([p.max() for p in planes], F)
+    n = int(total)
+    o = rng.uniform(lo * F(1.3), hi * F(1.3), size=(n, 3)).astype(F)
+    d = unit(rng.normal(size=(n, 3)))
+    offs = np.array([0.0, 0.5, -0.5, 1.0, -1.0], F) * pad
+    ulps = np.array([0, 1, -1, 2, -2, 8, -8])
+    ax = rng.integers(0, 3, n)
+    rows = np.arange(n)
+    for a in range(3):
+        m = ax == a
+        k = int(m.sum())
+        base = (rng.choice(planes[a], k) + rng.choice(offs, k)).astype(F)
+        o[m, a] = _ulp_step(base, rng.choice(ulps, k))
+    tiny = (rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-38, -8, n)).astype(F)
+    q = n // 4
+    # second component exactly zero (signed)
+    b = (ax[:q] + 1 + rng.integers(0, 2, q)) % 3
+    d[rows[:q], b] = 0
+    d[rows, ax] = 0
+    # origin in the margin of a second plane as well, that component tiny too
+    b2 = (ax[q:2 * q] + 1 + rng.integers(0, 2, q)) % 3
+    for a in range(3):
+        m = np.flatnonzero(b2 == a) + q
+        k = len(m)
+        base = (rng.choice(planes[a], k) + rng.choice(offs, k)).astype(F)
+        o[m, a] = _ulp_step(base, rng.choice(ulps, k))
+        d[m, a] = 0
+    d = unit(d)                                      # unit length from the O(1) components; the tiny ones do not change it
+    d[rows[:q], b] = rng.choice(np.array([0.0, -0.0], F), q)
+    d[rows[q:2 * q], b2] = (rng.choice([-1.0, 1.0], q) * 10.0 ** rng.uniform(-38, -8, q)).astype(F)
+    d[rows, ax] = tiny
+    repro_o = np.array([[-2.4999998, 4.998999, 7.5000014], [-3.1517425, 1.0000867e-3, -0.25229582]], F)
+    repro_d = np.array([[-1.5050732e-23, 0.0, -1.0], [1.0, -1.6739866e-14, 0.0]], F)
+    return np.ascontiguousarray(np.concatenate([o, repro_o])), np.ascontiguousarray(np.concatenate([d, repro_d]).astype(F))
+
+
+def far_origin_rays(flat, rng, n=1200):
+    """Round 3: origins 10 to 10^6 scene extents away, aimed at points inside the scene (and a few aimed past it).  At that distance
+    an ulp of the origin's coordinate exceeds any padding of the tree, and the reference's own arithmetic decides in that noise:
+    mcrt answers rays beyond MCRT_FAR_ORIGIN scene sizes with the reference's loop over all objects (include/mcrt.h)."""
+    tr = flat.triangles
+    lo = np.min([tr[k].min(axis=0) for k in ("v0", "v1", "v2")], axis=0).astype(F)
+    hi = np.max([tr[k].max(axis=0) for k in ("v0", "v1", "v2")], axis=0).astype(F)
+    extent = float((hi - lo).max())
+    tgt = rng.uniform(lo, hi, size=(n, 3))
+    dist = extent * 10.0 ** rng.uniform(1, 6, n)
+    o = (tgt + unit(rng.normal(size=(n, 3))).astype(np.float64) * dist[:, None]).astype(F)
+    o[::5, rng.integers(0, 3)] = 0.0                                   # far along two axes only
+    d = unit((tgt - o.astype(np.float64)).astype(F))
+    return np.ascontiguousarray(o), np.ascontiguousarray(d)
 
 
 def make_rays(R, scene, cam, flat, rng, n_random=6000, n_secondary=6000):
@@ -191,7 +263,10 @@ def hits_and_samples(R, name, scene, flat, cam, rng, n_samples):
     o, d = make_rays(R, scene, cam, flat, rng)
     # round 2: rays in the octree's split planes; their own generator, so every other fixture keeps its bytes
     so, sd = split_plane_rays(R, cam, flat, np.random.default_rng([20261111, len(name), n_samples]))
-    o, d = np.ascontiguousarray(np.concatenate([o, so])), np.ascontiguousarray(np.concatenate([d, sd]))
+    # round 3: the padding margins of the split planes and far origins; again their own generators
+    mo, md = pad_margin_rays(flat, np.random.default_rng([20261201, len(name), n_samples]))
+    fo, fd = far_origin_rays(flat, np.random.default_rng([20261202, len(name), n_samples]))
+    o, d = np.ascontiguousarray(np.concatenate([o, so, mo, fo])), np.ascontiguousarray(np.concatenate([d, sd, md, fd]))
     obj, elem, t = R.intersect(scene, o, d)
     save(f"hits_{name}.npz", origins=o, dirs=d, obj=obj, elem=elem, t=t)
     npix = cam.width * cam.height

@@ -592,9 +592,8 @@ static inline int sphere_hit(const mcrt_object* S, v3 o, v3 d, float* t)
 /* Scene::IntersectRay, source/scene.cpp:62-80, with TriangleMesh::Intersects,
  * source/objects/mesh.cpp:9-41. */
 static hit_t scene_hit_octree(const orc_scene* S, v3 o, v3 d, orc_stats* st);
-static inline hit_t scene_hit(const orc_scene* S, v3 o, v3 d, orc_stats* st)
+static inline hit_t scene_hit_brute(const orc_scene* S, v3 o, v3 d, orc_stats* st)
 {
-    if (S->tree) return scene_hit_octree(S, o, d, st);
     hit_t best = { -1, 0, FLT_MAX };
     if (st) st->rays++;
     for (uint32_t i = 0; i < S->nobj; ++i) {
@@ -618,6 +617,11 @@ static inline hit_t scene_hit(const orc_scene* S, v3 o, v3 d, orc_stats* st)
         }
     }
     return best;
+}
+static inline hit_t scene_hit(const orc_scene* S, v3 o, v3 d, orc_stats* st)
+{
+    if (S->tree) return scene_hit_octree(S, o, d, st);
+    return scene_hit_brute(S, o, d, st);
 }
 
 ORC_EXPORT void orc_intersect(const orc_scene* S, uint64_t n, const float* o, const float* d, int32_t* out_obj, uint32_t* out_elem,
@@ -701,6 +705,12 @@ static hit_t octree_hit(const orc_scene* S, const orc_octree* T, const uint32_t*
 {
     enum { STACK = 128 };
     uint64_t gate_known = 0, gate_pass = 0;
+    /* OctreeWalk::begin: an origin further out than far_limit = pad / (32 * FLT_EPSILON) (or not a number) is answered by the loop
+       over all objects - out there an ulp of the origin's coordinate is no longer small against the padding the walk decides with */
+    {
+        const float far_limit = T->pad * 262144.0f;
+        if (!(fabsf(ro.x) <= far_limit && fabsf(ro.y) <= far_limit && fabsf(ro.z) <= far_limit)) return scene_hit_brute(S, ro, rd, NULL);
+    }
     /* slab_rcp of csrc/mcrt_device.h: the reciprocal clamped to +-2^100 so that every product below stays finite */
     const float RCP_MAX = 1.2676506002282294e30f;
     float inv[3] = { 1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z }, padt[3];
@@ -708,7 +718,7 @@ static hit_t octree_hit(const orc_scene* S, const orc_octree* T, const uint32_t*
     uint32_t flip = 0;
     for (int a = 0; a < 3; ++a) {
         if (!(fabsf(inv[a]) <= RCP_MAX)) inv[a] = copysignf(RCP_MAX, dd[a]);
-        padt[a] = T->pad * fabsf(inv[a]);
+        padt[a] = (0.5f * T->pad) * fabsf(inv[a]);      /* SceneView::walk_pad: HALF the builder's padding, see OctreeWalk::visit */
         if (inv[a] < 0.0f) flip |= 1u << a;
     }
     const float oo[3] = { ro.x, ro.y, ro.z };

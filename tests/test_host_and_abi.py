@@ -442,3 +442,68 @@ def test_host_take_screenshot(host, tmp_path):
     assert np.array_equal(rgba, bgra[:, :, [2, 1, 0, 3]])
     assert host.mcrt_host_take_screenshot(str(tmp_path / "no_such_dir" / "x").encode(), bgra.ctypes.data, w, h, name, 512) == 1
     assert name.value == b""
+
+
+# ------------------------------------------------------------------ round 3: the walk's margin against its own rounding
+@pytest.mark.parametrize("name,accel", [("config4_2k", None), ("config4_2k", (1, 12, 0.0)), ("cornell", None), ("config3", (2, 6, 1e-6)), ("hexagon", None)])
+def test_octree_replay_on_pad_margin_rays(pkg, oracle, scene_of, name, accel):
+    """Fresh rays of the class that broke round 2's walk (origin a few ulps either side of split plane +- padding, one direction
+    component down to 1e-38: the ray stays in the margin for its whole length), levels 1-4 of the tree, plus far origins: the CPU
+    replay of the walk equals the brute force.  tools/fuzz_walk.py runs the same generator at 10^6 rays (and on the GPU)."""
+    import gen_golden as gg
+
+    flat = scene_of(name)
+    acc = pkg.AccelParams(*accel) if accel else None
+    rng = np.random.default_rng([31, len(name)])
+    o, d = gg.pad_margin_rays(flat, rng, total=40000, levels=4, accel=acc)
+    fo, fd = gg.far_origin_rays(flat, rng, n=2000)
+    o, d = np.concatenate([o, fo]), np.concatenate([d, fd])
+    sc = oracle.scene(flat)
+    want = oracle.intersect(sc, o, d)
+    info, box, words, refs = pkg.build_scene_image(flat, acc)
+    assert info.far_origin_limit == np.float32(info.pad) * np.float32(262144.0)
+    got = oracle.intersect_octree(sc, info, box, words, refs, o, d)
+    for g, w in zip(got, want):
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+    assert (want[0] >= 0).mean() > 0.5
+
+
+def test_verdict_round2_repro_rays(pkg, oracle, scene_of):
+    """The two rays of VERDICT.md (round 2): brute force (2, 3, 12.500001) and (0, 1, 8.151742); the replay of the walk said MISS."""
+    flat = scene_of("config4_2k")
+    o = np.array([[-2.4999998, 4.998999, 7.5000014], [-3.1517425, 1.0000867e-3, -0.25229582]], np.float32)
+    d = np.array([[-1.5050732e-23, 0.0, -1.0], [1.0, -1.6739866e-14, 0.0]], np.float32)
+    sc = oracle.scene(flat)
+    want = oracle.intersect(sc, o, d)
+    assert want[0].tolist() == [2, 0] and want[1].tolist() == [3, 1]
+    info, box, words, refs = pkg.build_scene_image(flat)
+    got = oracle.intersect_octree(sc, info, box, words, refs, o, d)
+    for g, w in zip(got, want):
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+
+
+def test_rccl_missing_is_reported_not_crashed(pkg):
+    """Where librccl cannot be loaded the three multi-GPU calls answer MCRT_ERR_NO_DEVICE with a message and nothing else is affected
+    (include/mcrt.h).  The miss is forced in a fresh process through MCRT_RCCL_LIB (no RCCL symbols in it: torch is not imported)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import ctypes as C, sys\n"
+        f"lib = C.CDLL({pkg.LIB_PATH!r})\n"
+        "lib.mcrt_last_error.restype = C.c_char_p\n"
+        "lib.mcrt_last_error.argtypes = [C.c_void_p]\n"
+        "comms = (C.c_void_p * 1)()\n"
+        "rc = lib.mcrt_comm_init_all(C.c_int(1), (C.c_int * 1)(0), comms)\n"
+        "msg = (lib.mcrt_last_error(None) or b'').decode()\n"
+        "rc2 = lib.mcrt_comm_destroy(C.c_void_p(1))\n"
+        "cam = (C.c_float * 22)()\n"
+        "ok = lib.mcrt_camera_look_at(C.c_uint32(4), C.c_uint32(4), C.c_float(90.0), (C.c_float * 3)(0, 0, 5), (C.c_float * 3)(0, 0, 0), (C.c_float * 3)(0, 1, 0), cam)\n"
+        "print(rc, rc2, ok, msg)\n"
+    )
+    env = dict(os.environ, MCRT_RCCL_LIB="/nonexistent/librccl.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rc, rc2, ok, msg = out.stdout.strip().split(" ", 3)
+    assert (rc, rc2, ok) == ("2", "2", "0")
+    assert "librccl not loadable" in msg and "/nonexistent/librccl.so" in msg
