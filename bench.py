@@ -18,6 +18,14 @@ and value = all samples of the step / max-over-ranks time.
 
 Default workload (BASELINE.json configs[1]): Cornell box + the 36-triangle box-stack mesh, 1024x1024,
 256 spp, depth 100.  Prints ONE JSON line on rank 0.
+
+At N = 1 the line also carries
+  "secondary"     the HBM-bound workload (config4_1024_16: the 1M-triangle mesh of BASELINE config 4, short run) timed in
+                  the same process after the headline - 1 warm-up + 3 steps - with its own `roofline` (bound "hbm"): the
+                  "traversal HBM GB/s" half of BASELINE's metric (--no-secondary leaves it out);
+  "cpu_baseline"  the reference's own TraceRay on the host cores, timed BEFORE the GPU phase (--no-cpu-baseline).
+Fields that come from a committed rocprofv3 pass (profiles/r*_pmc.json) are used only when that file records the
+SHA-256 of the very libmcrt_hip.so that is loaded now; otherwise they are left out and the line says so.
 """
 import argparse
 import json
@@ -47,6 +55,7 @@ WORKLOADS = {
     "config4_2048_256": ("config4", 2048, 2048, 256),       # BASELINE config 4: 1M-triangle mesh (octree, HBM/L2 bound)
     "config4_1024_16": ("config4", 1024, 1024, 16),         # the same scene, short run
 }
+SECONDARY = "config4_1024_16"                              # the HBM-bound workload every N = 1 run also times ("secondary")
 PASS_SPP = {"cornell_4k_4096": 64}                          # progressive workloads: samples per pass (one reduce + resolve each)
 
 
@@ -57,20 +66,37 @@ def algorithmic_bytes_per_sample(cnt, spp):
     return (cnt["nodes"] * 32 + cnt["tris"] * 36 + cnt["spheres"] * 16 + cnt["gates"] * 24) / s + 24.0 / spp + 4.0 / spp
 
 
-def committed_pmc(workload):
-    """(entry, repo-relative path) of the newest committed rocprofv3 PMC summary of this workload
+def lib_sha256(path):
+    import hashlib
+
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def committed_pmc(workload, lib_hash):
+    """(entry, repo-relative path, why-not) of the newest committed rocprofv3 PMC summary of this workload
     (profiles/r*_pmc.json, written by tools/summarize_profiles.py from separate --pmc passes of this very command).
-    Hardware counters cannot be read from inside this process; everything taken from here is tagged with its source."""
+    Hardware counters cannot be read from inside this process; everything taken from here is tagged with its source.
+    The summary records the SHA-256 of the library it profiled ("_lib_sha256"): counters of another binary say nothing
+    about this one, so an entry whose hash differs (or is missing) is not used."""
     import glob
 
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
         try:
-            entry = json.load(open(path)).get(workload)
+            doc = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if entry:
-            return entry, os.path.relpath(path, ROOT)
-    return None, None
+        entry = doc.get(workload)
+        if not entry:
+            continue
+        rel = os.path.relpath(path, ROOT)
+        if doc.get("_lib_sha256") != lib_hash:
+            return None, rel, f"{rel} profiled another build of libmcrt_hip.so (sha256 {str(doc.get('_lib_sha256'))[:16]}, loaded {lib_hash[:16]}): counter-derived fields left out"
+        return entry, rel, None
+    return None, None, "no committed PMC summary of this workload"
 
 
 def host_cpu_budget():
@@ -128,6 +154,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--accel", default="auto", choices=["auto", "octree", "scan", "brute", "flat"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="leave out the HBM-bound secondary workload (N = 1 runs time it after the headline)")
     ap.add_argument("--no-pmc-fields", action="store_true", help="leave out everything read from profiles/ (used while profiling)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -178,156 +205,193 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
 
-    scene_name, width, height, spp = WORKLOADS[args.workload]
-    if scene_name == "config4":
-        from mcrt_amd import scenes
-
-        note("building the 1,000,000-triangle mesh")
-        flat = scenes.config4(pkg.FlatScene.load(os.path.join(ROOT, "tests", "golden", "scene_cornell.npz")), n=1_000_000, seed=42)
-    else:
-        flat = pkg.FlatScene.load(os.path.join(ROOT, "tests", "golden", f"scene_{scene_name}.npz"))
-    cam = pkg.host_camera(width, height, 90.0, (0.0, 0.0, 5.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
-
+    lib_hash = lib_sha256(os.environ.get("MCRT_LIB") or pkg.LIB_PATH)
+    n_cu = torch.cuda.get_device_properties(device_index).multi_processor_count
     be = pkg.Backend(device_index)
     stream = torch.cuda.current_stream()
     be.set_stream(stream.cuda_stream)
-    be.upload_scene(flat)
-    be.set_camera(cam)
-    be.set_accel({"auto": pkg.ACCEL_AUTO, "octree": pkg.ACCEL_OCTREE, "scan": pkg.ACCEL_SCAN, "brute": pkg.ACCEL_BRUTE, "flat": pkg.ACCEL_FLAT}[args.accel])
-    accum = torch.zeros(height * width * 3, dtype=torch.float64, device="cuda")
-    be.bind_accumulator(accum.data_ptr())
 
-    # the sample plan of this rank: a list of passes (first global sample index, count) and the job's total spp
-    plan = sharding.SamplePlan(rank, world, spp, args.scaling, pass_spp=PASS_SPP.get(args.workload))
-    my_samples_per_step = sum(n for _, n in plan.passes)
+    def load_scene(scene_name):
+        if scene_name == "config4":
+            from mcrt_amd import scenes
 
-    def step():
-        be.clear()
-        for k, (first, count) in enumerate(plan.passes):
-            if count:
-                be.render(first, count, DEPTH, SEED)
-            # one collective per pass: the W*H*3 doubles of every rank summed into rank 0 (RCCL over xGMI), which resolves;
-            # the other ranks start their next pass from zero (their sums now live on rank 0)
-            if rehearse and dist is not None:
-                host = accum.cpu()
-                sharding.reduce_accumulator(host, dist, dst=0)
+            note("building the 1,000,000-triangle mesh")
+            return scenes.config4(pkg.FlatScene.load(os.path.join(ROOT, "tests", "golden", "scene_cornell.npz")), n=1_000_000, seed=42)
+        return pkg.FlatScene.load(os.path.join(ROOT, "tests", "golden", f"scene_{scene_name}.npz"))
+
+    def run_workload(workload, flat, steps, warmup, accel, scaling, device_build=False):
+        """Upload, warm up, time `steps` steps, then (outside the timed region) the duration of the dominant kernel launch and the
+        kernel's own work counters.  Returns the fields of one bench line."""
+        scene_name, width, height, spp = WORKLOADS[workload]
+        cam = pkg.host_camera(width, height, 90.0, (0.0, 0.0, 5.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
+        be.upload_scene(flat, device_build=device_build)
+        be.set_camera(cam)
+        be.set_accel({"auto": pkg.ACCEL_AUTO, "octree": pkg.ACCEL_OCTREE, "scan": pkg.ACCEL_SCAN, "brute": pkg.ACCEL_BRUTE, "flat": pkg.ACCEL_FLAT}[accel])
+        accum = torch.zeros(height * width * 3, dtype=torch.float64, device="cuda")
+        be.bind_accumulator(accum.data_ptr())
+
+        # the sample plan of this rank: a list of passes (first global sample index, count) and the job's total spp
+        plan = sharding.SamplePlan(rank, world, spp, scaling, pass_spp=PASS_SPP.get(workload))
+        my_samples_per_step = sum(n for _, n in plan.passes)
+
+        def step():
+            be.clear()
+            for k, (first, count) in enumerate(plan.passes):
+                if count:
+                    be.render(first, count, DEPTH, SEED)
+                # one collective per pass: the W*H*3 doubles of every rank summed into rank 0 (RCCL over xGMI), which resolves;
+                # the other ranks start their next pass from zero (their sums now live on rank 0)
+                if rehearse and dist is not None:
+                    host = accum.cpu()
+                    sharding.reduce_accumulator(host, dist, dst=0)
+                    if rank == 0:
+                        accum.copy_(host)
+                else:
+                    sharding.reduce_accumulator(accum, dist, dst=0)
+                if k + 1 < len(plan.passes):
+                    sharding.after_reduce(accum, dist, dst=0)
                 if rank == 0:
-                    accum.copy_(host)
-            else:
-                sharding.reduce_accumulator(accum, dist, dst=0)
-            if k + 1 < len(plan.passes):
-                sharding.after_reduce(accum, dist, dst=0)
-            if rank == 0:
-                be.resolve(pkg.TONEMAP_REINHARD, plan.spp_after(k + 1), want_mean=False)
+                    be.resolve(pkg.TONEMAP_REINHARD, plan.spp_after(k + 1), want_mean=False)
 
-    def fence():
+        def fence():
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            be.synchronize()
+
+        note(f"{workload}: scene uploaded; {len(plan.passes)} pass(es) of this rank per step, {my_samples_per_step} spp; warming up")
+        for _ in range(warmup):
+            step()
+        fence()
+        note(f"{workload}: timing")
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
         if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        be.synchronize()
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
 
-    note(f"scene uploaded; {len(plan.passes)} pass(es) of this rank per step, {my_samples_per_step} spp; warming up")
-    for _ in range(args.warmup):
-        step()
-    fence()
-    note("timing")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        note(f"{workload}: timed {steps} steps in {elapsed:.3f} s; measuring kernel time and counters")
+        # --- outside the timed region: duration of the dominant kernel launch (HIP events on the launch stream, recorded by
+        # the library around k_render) and the kernel's own work counters
+        first, count = max(plan.passes, key=lambda p: p[1])
+        k_ms = []
+        for _ in range(3):
+            be.clear(); be.render(first, count, DEPTH, SEED)
+            k_ms.append(be.last_render_ms())
+        k_ms = float(np.median(k_ms))
+        count_spp = min(count, 8)
+        be.set_counting(True)
+        be.clear(); be.render(first, count_spp, DEPTH, SEED)
+        cnt = be.counters()
+        be.set_counting(False)
+        info = be.octree_info()
+        be.bind_accumulator(0)                  # `accum` goes out of scope with this function
 
-    note(f"timed {args.steps} steps in {elapsed:.3f} s; measuring kernel time and counters")
-    # --- outside the timed region: duration of the dominant kernel launch (HIP events on the launch stream, recorded by
-    # the library around k_render) and the kernel's own work counters
-    first, count = max(plan.passes, key=lambda p: p[1])
-    k_ms = []
-    for _ in range(3):
-        be.clear(); be.render(first, count, DEPTH, SEED)
-        k_ms.append(be.last_render_ms())
-    k_ms = float(np.median(k_ms))
-    count_spp = min(count, 8)
-    be.set_counting(True)
-    be.clear(); be.render(first, count_spp, DEPTH, SEED)
-    cnt = be.counters()
-    be.set_counting(False)
-    info = be.octree_info()
+        samples_per_step = width * height * plan.total_spp
+        value = samples_per_step * steps / elapsed / 1e6
+        launch_samples = width * height * count
+        bytes_per_sample = algorithmic_bytes_per_sample(cnt, count)
+        launch_bytes = bytes_per_sample * launch_samples
+        hbm_achieved = launch_bytes / (k_ms * 1e-3) / 1e9
+        resident = bool(info.lds_resident) or len(flat.triangles) <= 256      # geometry served from SGPRs / LDS, not from HBM
+        pmc, pmc_path, pmc_why = (None, None, "not requested") if (args.no_pmc_fields or accel != "auto") else committed_pmc(workload, lib_hash)
 
-    samples_per_step = width * height * plan.total_spp
-    value = samples_per_step * args.steps / elapsed / 1e6
-    launch_samples = width * height * count
-    bytes_per_sample = algorithmic_bytes_per_sample(cnt, count)
-    launch_bytes = bytes_per_sample * launch_samples
-    hbm_achieved = launch_bytes / (k_ms * 1e-3) / 1e9
-    resident = bool(info.lds_resident) or len(flat.triangles) <= 256      # geometry served from SGPRs / LDS, not from HBM
-    n_cu = torch.cuda.get_device_properties(device_index).multi_processor_count
-    pmc, pmc_path = (None, None) if (args.no_pmc_fields or args.accel != "auto") else committed_pmc(args.workload)
+        per_sample = {k: round(v / max(cnt["samples"], 1), 4) for k, v in cnt.items() if k != "samples"}
+        hbm_algorithmic = {"achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 6),
+                           "algorithmic_bytes_per_sample": round(bytes_per_sample, 2), "per_sample": per_sample}
+        if resident:
+            # VALU-bound kernel: achieved = wave-level VALU instructions per second, peak = every SIMD issuing one wave64
+            # VALU instruction every 2 cycles at the peak clock.  The instruction count per sample is a hardware counter
+            # (SQ_INSTS_VALU of the committed PMC pass of this workload and this binary); the launch duration is measured here.
+            valu_peak = n_cu * 4 * PEAK_CLOCK_HZ / VALU_CYCLES_PER_WAVE_INSTR / 1e9
+            roof = {"bound": "valu", "achieved": None, "peak": round(valu_peak, 1), "unit": "G wave-instr/s", "frac": None, "traffic": None,
+                    "kernel": "k_render", "kernel_ms": round(k_ms, 4)}
+            if pmc and pmc.get("valu_insts_per_sample"):
+                achieved = pmc["valu_insts_per_sample"] * launch_samples / (k_ms * 1e-3) / 1e9
+                roof.update({
+                    "achieved": round(achieved, 2), "frac": round(achieved / valu_peak, 4),
+                    "traffic": pmc.get("traffic_bytes_per_sample") and int(pmc["traffic_bytes_per_sample"] * launch_samples),
+                    "valu_insts_per_sample": pmc["valu_insts_per_sample"], "active_lanes_per_valu_instruction": pmc.get("active_lanes_per_valu_instruction"),
+                    "valu_cycle_weighted_frac_in_profile": pmc.get("valu_cycle_weighted_frac"),
+                    "source": f"{pmc_path}: valu_insts_per_sample, traffic_bytes_per_sample, active_lanes (rocprofv3 --pmc passes of this command on this binary, sha256 {lib_hash[:16]}); kernel_ms measured in this run",
+                })
+            else:
+                roof["pmc"] = pmc_why
+            roof["hbm_algorithmic"] = hbm_algorithmic
+            roof["note"] = ("scene tables live in SGPRs / LDS, so the kernel is bound by VALU issue, not by HBM: frac = SQ_INSTS_VALU x 2 cycles / "
+                            "(CUs x 4 SIMDs x 2.4 GHz x kernel time).  hbm_algorithmic is SURVEY.md 8(d)'s byte figure (one record per test, served "
+                            "on chip) against the HBM peak, kept as a secondary: it is not a bound and may exceed 1")
+        else:
+            roof = {"bound": "hbm", "achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 6),
+                    "traffic": None, "kernel": "k_render", "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_sample": round(bytes_per_sample, 2),
+                    "per_sample": per_sample}
+            if pmc:
+                roof.update({"traffic": pmc.get("traffic_bytes_per_sample") and int(pmc["traffic_bytes_per_sample"] * launch_samples),
+                             "active_lanes_per_valu_instruction": pmc.get("active_lanes_per_valu_instruction"),
+                             "source": f"{pmc_path}: traffic_bytes_per_sample, active_lanes (rocprofv3 --pmc passes of this command on this binary, sha256 {lib_hash[:16]}); kernel_ms and counts measured in this run"})
+            else:
+                roof["pmc"] = pmc_why
+            roof["note"] = ("scene image (%.0f MB) is walked from HBM / L2 by divergent lanes; achieved = SURVEY.md 8(d) algorithmic bytes / kernel time"
+                            % (info.blob_bytes / 1e6))
+        return {
+            "value": round(value, 3),
+            "unit": "Msamples/s",
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "config": {
+                "workload": (f"{workload}: {scene_name} scene, {width}x{height}, "
+                             + (f"{spp} spp per GPU" if scaling == "weak" else f"{spp} spp in total, split over {world} GPU(s)")
+                             + f", depth {DEPTH}, accel {accel}"),
+                "objects": int(len(flat.objects)), "triangles": int(len(flat.triangles)), "octree_nodes": int(info.node_count),
+                "scene_in_lds": bool(info.lds_resident), "lanes_per_pixel": be.lanes_per_pixel(count), "passes_per_step": len(plan.passes),
+                "total_spp": plan.total_spp, "parallelism": f"spp-sharded x{world}",
+            },
+            "roofline": roof,
+        }
 
-    per_sample = {k: round(v / max(cnt["samples"], 1), 4) for k, v in cnt.items() if k != "samples"}
-    hbm_algorithmic = {"achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 6),
-                       "algorithmic_bytes_per_sample": round(bytes_per_sample, 2), "per_sample": per_sample}
-    if resident:
-        # VALU-bound kernel: achieved = wave-level VALU instructions per second, peak = every SIMD issuing one wave64
-        # VALU instruction every 2 cycles at the peak clock.  The instruction count per sample is a hardware counter
-        # (SQ_INSTS_VALU of the committed PMC pass of this workload); the launch duration is measured here.
-        valu_peak = n_cu * 4 * PEAK_CLOCK_HZ / VALU_CYCLES_PER_WAVE_INSTR / 1e9
-        roof = {"bound": "valu", "achieved": None, "peak": round(valu_peak, 1), "unit": "G wave-instr/s", "frac": None, "traffic": None,
-                "kernel": "k_render", "kernel_ms": round(k_ms, 4)}
-        if pmc and pmc.get("valu_insts_per_sample"):
-            achieved = pmc["valu_insts_per_sample"] * launch_samples / (k_ms * 1e-3) / 1e9
-            roof.update({
-                "achieved": round(achieved, 2), "frac": round(achieved / valu_peak, 4),
-                "traffic": pmc.get("traffic_bytes_per_sample") and int(pmc["traffic_bytes_per_sample"] * launch_samples),
-                "valu_insts_per_sample": pmc["valu_insts_per_sample"], "active_lanes_per_valu_instruction": pmc.get("active_lanes_per_valu_instruction"),
-                "valu_cycle_weighted_frac_in_profile": pmc.get("valu_cycle_weighted_frac"),
-                "source": f"{pmc_path}: valu_insts_per_sample, traffic_bytes_per_sample, active_lanes (rocprofv3 --pmc passes of this command); kernel_ms measured in this run",
-            })
-        roof["hbm_algorithmic"] = hbm_algorithmic
-        roof["note"] = ("scene tables live in SGPRs / LDS, so the kernel is bound by VALU issue, not by HBM: frac = SQ_INSTS_VALU x 2 cycles / "
-                        "(CUs x 4 SIMDs x 2.4 GHz x kernel time).  hbm_algorithmic is SURVEY.md 8(d)'s byte figure (one record per test, served "
-                        "on chip) against the HBM peak, kept as a secondary: it is not a bound and may exceed 1")
-    else:
-        roof = {"bound": "hbm", "achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 6),
-                "traffic": None, "kernel": "k_render", "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_sample": round(bytes_per_sample, 2),
-                "per_sample": per_sample}
-        if pmc:
-            roof.update({"traffic": pmc.get("traffic_bytes_per_sample") and int(pmc["traffic_bytes_per_sample"] * launch_samples),
-                         "active_lanes_per_valu_instruction": pmc.get("active_lanes_per_valu_instruction"),
-                         "source": f"{pmc_path}: traffic_bytes_per_sample, active_lanes (rocprofv3 --pmc passes of this command); kernel_ms and counts measured in this run"})
-        roof["note"] = ("scene image (%.0f MB) is walked from HBM / L2 by divergent lanes; achieved = SURVEY.md 8(d) algorithmic bytes / kernel time"
-                        % (info.blob_bytes / 1e6))
+    scene_name, width, height, _ = WORKLOADS[args.workload]
+    flat = load_scene(scene_name)
 
+    # The CPU baseline runs FIRST (host cores only), so that the GPU phase - headline, then the secondary - is the last
+    # and uninterrupted stretch of the run.
+    baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        note("timing the CPU baseline on the host cores")
+        baseline = cpu_baseline(pkg, flat, scene_name, width, height, note)
+
+    head = run_workload(args.workload, flat, args.steps, args.warmup, args.accel, args.scaling)
     out = {
-        "metric": "Msamples/s (whole node) Cornell box; traversal HBM GB/s",
-        "value": round(value, 3),
+        "metric": "Msamples/s (whole node) Cornell box at 1/2/4/8 GPU; traversal HBM GB/s",
+        "value": head["value"],
         "unit": "Msamples/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "ms_per_step": head["ms_per_step"],
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32 geometry / f64 radiance",
         "data": "synthetic",
-        "config": {
-            "workload": (f"{args.workload}: {scene_name} scene, {width}x{height}, "
-                         + (f"{spp} spp per GPU" if args.scaling == "weak" else f"{spp} spp in total, split over {world} GPU(s)")
-                         + f", depth {DEPTH}, accel {args.accel}"),
-            "objects": int(len(flat.objects)), "triangles": int(len(flat.triangles)), "octree_nodes": int(info.node_count),
-            "scene_in_lds": bool(info.lds_resident), "lanes_per_pixel": be.lanes_per_pixel(count), "passes_per_step": len(plan.passes),
-            "total_spp": plan.total_spp, "parallelism": f"spp-sharded x{world}",
-        },
-        "roofline": roof,
+        "config": head["config"],
+        "roofline": head["roofline"],
+        "lib_sha256": lib_hash,
     }
+    if baseline is not None:
+        out["cpu_baseline"] = baseline
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        note("timing the CPU baseline on the host cores")
-        out["cpu_baseline"] = cpu_baseline(pkg, flat, scene_name, width, height, note)
+    # The HBM-bound half of the metric ("traversal HBM GB/s"): the 1M-triangle scene of BASELINE config 4, short run, timed
+    # here so that the driver's own run carries it.  The octree is built on the device (45 ms; the host build takes 1.7 s).
+    if world == 1 and not args.no_secondary and args.workload != SECONDARY and args.accel == "auto":
+        flat2 = load_scene(WORKLOADS[SECONDARY][0])
+        sec = run_workload(SECONDARY, flat2, 3, 1, "auto", "weak", device_build=True)
+        sec["metric"] = "Msamples/s on the HBM-resident scene; roofline.achieved = traversal GB/s (SURVEY.md 8d algorithmic bytes / k_render time)"
+        out["secondary"] = sec
 
     if rank == 0:
         print(json.dumps(out), flush=True)

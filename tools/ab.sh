@@ -8,7 +8,7 @@ for spec in "$@"; do
   name=${spec%%:*}; envs=""
   if [[ "$spec" == *:* ]]; then envs=$(echo "${spec#*:}" | tr ',' ' '); fi
   out=gpurun_out/ab_${name}_$(echo "$envs" | tr ' =' '__')_$round
-  env $envs MCRT_LIB=$GRAFT_REPO_ROOT/build/ab/$name.so timeout -k 10 300 python bench.py --workload $W --steps $S --warmup 1 --no-cpu-baseline --no-pmc-fields > $out.json 2> $out.err || { tail -5 $out.err; exit 1; }
+  env $envs MCRT_LIB=$GRAFT_REPO_ROOT/build/ab/$name.so timeout -k 10 300 python bench.py --workload $W --steps $S --warmup 1 --no-cpu-baseline --no-secondary --no-pmc-fields > $out.json 2> $out.err || { tail -5 $out.err; exit 1; }
   python - "$out.json" "$spec" <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -3,7 +3,7 @@
 # usage: tools/prof_kernels.sh <workload> <outtag>     (environment passes through)
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --workload $1 --steps 1 --warmup 0 --no-cpu-baseline --no-pmc-fields"
+B="python3 $ROOT/bench.py --workload $1 --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --no-pmc-fields"
 timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/$2_a -- $B > /dev/null 2> $OUT/$2_a.err || exit 1
 timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_BUSY_CYCLES SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/$2_b -- $B > /dev/null 2> $OUT/$2_b.err || exit 1
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/$2_c -- $B > /dev/null 2> $OUT/$2_c.err

@@ -4,7 +4,7 @@
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out
 [ "$1" != "-" ] && export MCRT_LIB=$ROOT/build/libmcrt_$1.so
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --workload $2 --steps 2 --warmup 1 --no-cpu-baseline --no-pmc-fields"
+B="python3 $ROOT/bench.py --workload $2 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-pmc-fields"
 timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/$3_a -- $B > /dev/null 2> $OUT/$3_a.err || exit 1
 timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/$3_b -- $B > /dev/null 2> $OUT/$3_b.err || exit 1
 timeout -s KILL 300 rocprofv3 --pmc TA_BUSY_avr TA_TA_BUSY_sum --output-format csv -d $OUT/$3_c -- $B > /dev/null 2> $OUT/$3_c.err

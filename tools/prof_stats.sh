@@ -3,7 +3,7 @@
 # usage: tools/prof_stats.sh <workload> <outtag>
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$2 -- python3 $ROOT/bench.py --workload $1 --steps 2 --warmup 1 --no-cpu-baseline --no-pmc-fields > $OUT/$2.json 2> $OUT/$2.err || exit 1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$2 -- python3 $ROOT/bench.py --workload $1 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-pmc-fields > $OUT/$2.json 2> $OUT/$2.err || exit 1
 python3 - <<PY
 import csv,glob
 for f in glob.glob("$OUT/$2/*/*_kernel_stats.csv"):

@@ -114,6 +114,10 @@ for w in workloads:
     if "GRBM_GUI_ACTIVE" in sq and secs:
         entry["effective_clock_ghz"] = round(sq["GRBM_GUI_ACTIVE"] / 8 / secs / 1e9, 3)
     out[w] = entry
+    if bench and bench.get("lib_sha256"):
+        if out.get("_lib_sha256", bench["lib_sha256"]) != bench["lib_sha256"]:
+            raise SystemExit(f"{w} was profiled with another build of libmcrt_hip.so than the workloads before it")
+        out["_lib_sha256"] = bench["lib_sha256"]       # bench.py uses this summary only with the same binary loaded
 out["_notes"] = ("Per k_render launch (median over the full-spp launches of one `bench.py --workload W` run per rocprofv3 pass; passes are separate "
                  "runs: sq1, sq2, FETCH_SIZE, WRITE_SIZE, GRBM_GUI_ACTIVE, kernel-trace stats). FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is "
                  "doubled (gfx950 reports half the bytes read, MI355X_MICROARCH.md). valu_frac_in_profile = SQ_INSTS_VALU x 2 cycles / "
