@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--accel", default="auto", choices=["auto", "octree", "scan", "brute", "flat"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spp", type=int, default=0, help="override the workload's samples per pixel (rehearsals of the progressive workloads at a reduced pass count; the line says so)")
     ap.add_argument("--no-secondary", action="store_true", help="leave out the HBM-bound secondary workload (N = 1 runs time it after the headline)")
     ap.add_argument("--no-pmc-fields", action="store_true", help="leave out everything read from profiles/ (used while profiling)")
     args = ap.parse_args()
@@ -223,6 +224,8 @@ def main():
         """Upload, warm up, time `steps` steps, then (outside the timed region) the duration of the dominant kernel launch and the
         kernel's own work counters.  Returns the fields of one bench line."""
         scene_name, width, height, spp = WORKLOADS[workload]
+        if args.spp > 0 and workload == args.workload:
+            spp = args.spp
         cam = pkg.host_camera(width, height, 90.0, (0.0, 0.0, 5.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
         be.upload_scene(flat, device_build=device_build)
         be.set_camera(cam)
@@ -346,7 +349,7 @@ def main():
             "config": {
                 "workload": (f"{workload}: {scene_name} scene, {width}x{height}, "
                              + (f"{spp} spp per GPU" if scaling == "weak" else f"{spp} spp in total, split over {world} GPU(s)")
-                             + f", depth {DEPTH}, accel {accel}"),
+                             + f", depth {DEPTH}, accel {accel}" + (" (spp overridden with --spp)" if spp != WORKLOADS[workload][3] else "")),
                 "objects": int(len(flat.objects)), "triangles": int(len(flat.triangles)), "octree_nodes": int(info.node_count),
                 "scene_in_lds": bool(info.lds_resident), "lanes_per_pixel": be.lanes_per_pixel(count), "passes_per_step": len(plan.passes),
                 "total_spp": plan.total_spp, "parallelism": f"spp-sharded x{world}",

@@ -655,6 +655,13 @@ typedef struct orc_octree {
 } orc_octree;
 
 typedef struct orc_octree_stats { uint64_t rays, nodes, tris, spheres, gates; } orc_octree_stats;
+#ifdef ORC_WALK_DEBUG
+/* experiment builds only (tools/exp_walk_stats.py): where the steps of a walk go */
+ORC_EXPORT uint64_t orc_walk_dbg[32];
+#define WALK_DBG(i, n) (orc_walk_dbg[i] += (uint64_t)(n))
+#else
+#define WALK_DBG(i, n) ((void)0)
+#endif
 
 struct orc_tree {
     orc_octree view;
@@ -732,7 +739,7 @@ static hit_t octree_hit(const orc_scene* S, const orc_octree* T, const uint32_t*
     while (sp > 0) {
         --sp;
         uint32_t node = stack_node[sp];
-        if (stack_t[sp] > best.t) continue;
+        if (stack_t[sp] > best.t) { WALK_DBG(0, 1); continue; }      /* popped behind the best hit */
         if (st) st->nodes++;
         float tb0 = 0.0f, tb1 = best.t;         /* the stretch of the ray inside the node's tight box */
         {
@@ -741,9 +748,10 @@ static hit_t octree_hit(const orc_scene* S, const orc_octree* T, const uint32_t*
                 float x = (b[a] - oo[a]) * inv[a], y = (b[3 + a] - oo[a]) * inv[a];
                 tb0 = fmaxf(tb0, fminf(x, y)); tb1 = fminf(tb1, fmaxf(x, y));
             }
-            if (!(tb0 <= tb1)) continue;
+            if (!(tb0 <= tb1)) { WALK_DBG(1, 1); continue; }         /* fetched, tight box missed */
         }
         uint32_t cw = T->words[2 * (size_t)node];
+        WALK_DBG(2, 1);
         uint32_t base = cw & 0x00FFFFFFu, mask = cw >> 24;
         if (mask) {
             /* OctreeWalk::visit, csrc/mcrt_device.h: the octant the ray is in at tb0 plus one per mid plane crossed before tb1, in ray
@@ -769,12 +777,16 @@ static hit_t octree_hit(const orc_scene* S, const orc_octree* T, const uint32_t*
                 if (!(mask & (1u << oct))) continue;
                 const uint32_t child = base + (uint32_t)__builtin_popcount(mask & ((1u << oct) - 1u));
                 if (sp < STACK) { stack_node[sp] = child; stack_t[sp] = t_in; ++sp; } else *overflow = 1;
+                WALK_DBG(4, 1);
             }
+            WALK_DBG(3, 1);                                          /* interior visits */
         }
         uint32_t ref = T->words[2 * (size_t)node + 1];
         if (ref != 0xFFFFFFFFu) {
             uint32_t e;
+            WALK_DBG(5, 1);                                          /* visits with a list */
             do {
+                WALK_DBG(6, 1);
                 e = T->refs[ref++];
                 uint32_t prim = e & 0x7FFFFFFFu;
                 uint32_t ob = prim_obj[prim], el = prim - first_prim[ob];

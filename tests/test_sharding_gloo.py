@@ -150,3 +150,30 @@ def test_rank_ranges_partition_the_samples(pkg):
         assert sharding.total_spp(world, 256) == 256 * world
     with pytest.raises(ValueError):
         sharding.rank_sample_range(2, 2, 4)
+
+
+def test_baseline_plans_for_eight_gpus(pkg):
+    """The sample plans bench.py builds for BASELINE configs 3 and 5 on 8 GPUs (strong scaling) and for config 4 (weak): same number of
+    passes on every rank (each ends in the one reduce), every global sample index rendered once, rank 0's running count per pass."""
+    import importlib.util
+
+    from mcrt_amd import sharding
+
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for workload, scaling, want_passes, want_total in (("config3_1024_1024", "strong", 1, 1024), ("cornell_4k_4096", "strong", 64, 4096),
+                                                       ("config4_2048_256", "weak", 1, 2048), ("config2_1024_256", "weak", 1, 2048)):
+        spp = bench.WORKLOADS[workload][3]
+        plans = [sharding.SamplePlan(r, 8, spp, scaling, pass_spp=bench.PASS_SPP.get(workload)) for r in range(8)]
+        assert all(len(p.passes) == want_passes for p in plans) and plans[0].total_spp == want_total
+        covered = np.zeros(want_total, np.int32)
+        for p in plans:
+            for b, n in p.passes:
+                covered[b:b + n] += 1
+        assert (covered == 1).all()
+        if workload == "cornell_4k_4096":
+            assert all(n == 8 for p in plans for _, n in p.passes)              # a 64-spp window over 8 ranks
+            assert [plans[0].spp_after(k) for k in (1, 2, 64)] == [64, 128, 4096]
+        if workload == "config3_1024_1024":
+            assert [p.passes[0] for p in plans] == [(128 * r, 128) for r in range(8)]
