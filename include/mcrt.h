@@ -243,6 +243,38 @@ int mcrt_intersect_device(mcrt_ctx* ctx, uint64_t n, const float* d_origins,
 int mcrt_intersect_noalloc(mcrt_ctx* ctx, uint64_t n, const float* origins, const float* dirs,
                            int32_t* out_obj, uint32_t* out_elem, float* out_t);
 
+/* ---- the per-object virtuals of class Object, source/objects/object.h:23-29,
+ * and Material::BRDF, on batches (host buffers).  The host mirror's
+ * Object::Intersects / GetSurfaceNormal / GetRandomPointOnSurface and
+ * Material::BRDF forward single calls to these.
+ *
+ * mcrt_object_intersect: Object::Intersects(rayOrigin, rayDirection, hitInfo)
+ * (object.h:23) of object `object_index` of the uploaded scene alone -
+ * SphereObject::Intersects (sphere.h:16-52) or TriangleMesh::Intersects
+ * (mesh.cpp:9-41: AABB gate, then every triangle, the first of the nearest
+ * wins) - for n rays.  out_hit[i] = 1 / 0 (the bool it returns), out_elem /
+ * out_t = hitInfo.elementIndex / hitDistance after the call (0 / FLT_MAX on a
+ * miss: RayIntersectionInfo::Reset, ray.h:24-29).
+ * mcrt_surface_normals: Object::GetSurfaceNormal(location, index) (object.h:24;
+ * sphere.h:54-57 normalize(location - position), mesh.cpp:43-46 the stored face
+ * normal) for n (object, element, location) triples; out = n*3 floats.
+ * mcrt_random_surface_points: Object::GetRandomPointOnSurface(gen)
+ * (object.h:26-29 the position; light.h:47-53 the quad's central quarter;
+ * sphere.h:59-69) - one point of object `object_index` per generator state;
+ * rng_states: n*2 uint64 in, advanced on return (0 or 2 draws each).
+ * mcrt_brdf: Material::BRDF(incident, reflection, normal),
+ * source/core/material.h:24-53 (Lambertian: albedo; Oren-Nayar with the
+ * kernels' fixed-order trigonometry, within 1 ulp of libm's), n direction
+ * triples; out = n doubles.  Needs no scene. */
+int mcrt_object_intersect(mcrt_ctx* ctx, uint32_t object_index, uint64_t n, const float* origins,
+                          const float* dirs, uint8_t* out_hit, uint32_t* out_elem, float* out_t);
+int mcrt_surface_normals(mcrt_ctx* ctx, uint64_t n, const uint32_t* objects, const uint32_t* elems,
+                         const float* positions, float* out_normals);
+int mcrt_random_surface_points(mcrt_ctx* ctx, uint32_t object_index, uint64_t n, uint64_t* rng_states,
+                               float* out_points);
+int mcrt_brdf(mcrt_ctx* ctx, const mcrt_material* material, uint64_t n, const float* incident,
+              const float* reflection, const float* normal, double* out);
+
 /* Per-sample radiance, i.e. one iteration of the spp loop of
  * source/main.cpp:122-139 without the Accumulate: jitter, GetPixelRay,
  * Scene::TraceRay (source/scene.cpp:94-234) with max_depth.  Sample k uses

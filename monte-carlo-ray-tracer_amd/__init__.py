@@ -25,6 +25,7 @@ ABI_SYMBOLS = (
     "mcrt_clear", "mcrt_dropped_samples", "mcrt_bind_accumulator", "mcrt_accumulator", "mcrt_render", "mcrt_last_render_ms", "mcrt_resolve",
     "mcrt_read_accumulator", "mcrt_write_accumulator", "mcrt_synchronize", "mcrt_octree_info_get", "mcrt_octree_download", "mcrt_set_counting", "mcrt_counters",
     "mcrt_lanes_per_pixel", "mcrt_set_lanes_per_pixel", "mcrt_reduce", "mcrt_comm_init_all", "mcrt_comm_destroy", "mcrt_add_accumulator",
+    "mcrt_object_intersect", "mcrt_surface_normals", "mcrt_random_surface_points", "mcrt_brdf",
     "mcrt_camera_look_at", "mcrt_scene_image_create", "mcrt_scene_image_destroy", "mcrt_scene_image_info", "mcrt_scene_image_octree",
 )
 
@@ -218,6 +219,33 @@ class Backend:
     def intersect_device(self, n, d_origins, d_dirs, d_obj, d_elem, d_t):
         """All arguments are raw device addresses (ints)."""
         self._ck(self.lib.mcrt_intersect_device(self.ctx, C.c_uint64(n), C.c_void_p(d_origins), C.c_void_p(d_dirs), C.c_void_p(d_obj), C.c_void_p(d_elem), C.c_void_p(d_t)))
+
+    def object_intersect(self, object_index, origins, dirs):
+        """Object::Intersects of one object of the scene: (hit bool array, elementIndex, hitDistance)."""
+        o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)
+        n = len(o)
+        hit = np.zeros(n, np.uint8); elem = np.zeros(n, np.uint32); t = np.zeros(n, np.float32)
+        self._ck(self.lib.mcrt_object_intersect(self.ctx, C.c_uint32(object_index), C.c_uint64(n), _ptr(o, C.c_float), _ptr(d, C.c_float), _ptr(hit, C.c_uint8), _ptr(elem, C.c_uint32), _ptr(t, C.c_float)))
+        return hit.astype(bool), elem, t
+
+    def surface_normals(self, objects, elems, positions):
+        ob = np.ascontiguousarray(objects, np.uint32); el = np.ascontiguousarray(elems, np.uint32); pos = _f32(positions).reshape(-1, 3)
+        out = np.zeros((len(ob), 3), np.float32)
+        self._ck(self.lib.mcrt_surface_normals(self.ctx, C.c_uint64(len(ob)), _ptr(ob, C.c_uint32), _ptr(el, C.c_uint32), _ptr(pos, C.c_float), _ptr(out, C.c_float)))
+        return out
+
+    def random_surface_points(self, object_index, states):
+        """Object::GetRandomPointOnSurface; returns (points, advanced generator states)."""
+        st = np.array(states, dtype=np.uint64).reshape(-1, 2).copy()
+        out = np.zeros((len(st), 3), np.float32)
+        self._ck(self.lib.mcrt_random_surface_points(self.ctx, C.c_uint32(object_index), C.c_uint64(len(st)), _ptr(st, C.c_uint64), _ptr(out, C.c_float)))
+        return out, st
+
+    def brdf(self, material, incident, reflection, normal):
+        i, r, n = _f32(incident).reshape(-1, 3), _f32(reflection).reshape(-1, 3), _f32(normal).reshape(-1, 3)
+        out = np.zeros(len(i), np.float64)
+        self._ck(self.lib.mcrt_brdf(self.ctx, C.byref(material), C.c_uint64(len(i)), _ptr(i, C.c_float), _ptr(r, C.c_float), _ptr(n, C.c_float), _ptr(out, C.c_double)))
+        return out
 
     def trace_samples(self, pixels, samples, seed, max_depth):
         px = np.ascontiguousarray(pixels, np.uint32); sm = np.ascontiguousarray(samples, np.uint32)

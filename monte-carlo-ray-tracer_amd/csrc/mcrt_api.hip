@@ -1019,6 +1019,90 @@ __global__ __launch_bounds__(kBlock) void k_unlit(const SceneView v, const Camer
     }
 }
 
+// ---- the per-object virtuals of class Object (source/objects/object.h:23-29) on ray / point batches: what the host mirror's
+// Object::Intersects, GetSurfaceNormal, GetRandomPointOnSurface and Material::BRDF forward to.  SMALL is staged in LDS, BIG read in place.
+
+// Object::Intersects of ONE object: SphereObject::Intersects (source/objects/sphere.h:16-52) or TriangleMesh::Intersects
+// (source/objects/mesh.cpp:9-41: the AABB gate, then every triangle, the first of the nearest kept).
+__global__ __launch_bounds__(kBlock) void k_object_intersect(const SceneView v, uint32_t obj, uint64_t n, const float* __restrict__ o, const float* __restrict__ d,
+                                                             uint8_t* __restrict__ out_hit, uint32_t* __restrict__ out_elem, float* __restrict__ out_t)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    stage_scene<false>(v, smem);
+    const LdsPtr sm = (LdsPtr)smem;
+    const GlbPtr big = v.big_img;
+    const uint32_t orec = v.off_obj + obj * OBJ_STRIDE;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const V3 ro = mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        bool hit = false;
+        uint32_t elem = 0;
+        float t = kFltMax;
+        if (sm[orec + OBJ_KIND] == (uint32_t)MCRT_OBJECT_SPHERE) {
+            float ts;
+            if (sphere_hit(sm, orec, ro, rd, ts)) { hit = true; t = ts; }
+        } else if (gate_hit(sm, orec, ro, rd)) {
+            const uint32_t first = sm[orec + OBJ_FIRST_TRI], count = sm[orec + OBJ_TRI_COUNT];
+            float nearest = kFltMax, hitDistance = kFltMax;
+            for (uint32_t k = 0; k < count; ++k)
+                if (tri_hit(big, v.off_tri + (first + k) * TRI_STRIDE, ro, rd, hitDistance) && hitDistance < nearest) { nearest = hitDistance; elem = k; }
+            if (nearest < kFltMax) { hit = true; t = nearest; } else elem = 0;
+        }
+        out_hit[i] = hit ? 1 : 0; out_elem[i] = elem; out_t[i] = t;
+    }
+}
+
+// Object::GetSurfaceNormal(location, index): source/objects/sphere.h:54-57, source/objects/mesh.cpp:43-46
+__global__ __launch_bounds__(kBlock) void k_surface_normals(const SceneView v, uint64_t n, const uint32_t* __restrict__ objs, const uint32_t* __restrict__ elems,
+                                                            const float* __restrict__ pos, float* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    stage_scene<false>(v, smem);
+    const LdsPtr sm = (LdsPtr)smem;
+    const GlbPtr big = v.big_img;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Hit h; h.prim = 0; h.obj = objs[i]; h.elem = elems[i]; h.t = 0.0f;
+        const V3 nrm = surface_normal(sm, big, v, h, mk(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]));
+        out[3 * i] = nrm.x; out[3 * i + 1] = nrm.y; out[3 * i + 2] = nrm.z;
+    }
+}
+
+// Object::GetRandomPointOnSurface(gen): Light (source/objects/light.h:47-53), SphereObject (source/objects/sphere.h:59-69), base
+// Object (source/objects/object.h:26-29); the generator states come in and go back advanced, like the by-reference generator
+__global__ __launch_bounds__(kBlock) void k_surface_points(const SceneView v, uint32_t obj, uint64_t n, uint64_t* __restrict__ states, float* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    stage_scene<false>(v, smem);
+    const LdsPtr sm = (LdsPtr)smem;
+    const uint32_t orec = v.off_obj + obj * OBJ_STRIDE;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Rng g; g.s0 = states[2 * i]; g.s1 = states[2 * i + 1];
+        const V3 p = light_point(sm, orec, g);
+        states[2 * i] = g.s0; states[2 * i + 1] = g.s1;
+        out[3 * i] = p.x; out[3 * i + 1] = p.y; out[3 * i + 2] = p.z;
+    }
+}
+
+// Material::BRDF(incident, reflection, normal), source/core/material.h:24-53, through the kernels' own brdf2 (the material's
+// fields are laid out as the object record brdf2 reads)
+__global__ __launch_bounds__(kBlock) void k_brdf(uint32_t diffuse, float albedo, float on_a, float on_b, uint64_t n, const float* __restrict__ inc,
+                                                 const float* __restrict__ refl, const float* __restrict__ nrm, double* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t rec[OBJ_STRIDE];
+    if (threadIdx.x == 0) { rec[OBJ_DIFFUSE] = diffuse; rec[OBJ_ALBEDO] = __float_as_uint(albedo); rec[OBJ_ON_A] = __float_as_uint(on_a); rec[OBJ_ON_B] = __float_as_uint(on_b); }
+    __syncthreads();
+    const LdsPtr sm = (LdsPtr)rec;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double f0, f1;
+        brdf2(sm, 0u, mk(inc[3 * i], inc[3 * i + 1], inc[3 * i + 2]), mk(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]), true,
+              mk(refl[3 * i], refl[3 * i + 1], refl[3 * i + 2]), false, mk(0, 0, 0), f0, f1);
+        out[i] = f0;
+    }
+}
+
 // source/main.cpp:142-164 + GLImageBuffer::SetPixel (source/opengl/data.cpp:28-50).  pow / exp are the fixed-order pm_pow / pm_exp:
 // the bytes equal the oracle's (portable mode) on every input, and libm's wherever 255 * pow is not within ~1e-13 of an integer.
 __global__ __launch_bounds__(kBlock) void k_resolve(const double* __restrict__ sums, uint64_t npix, double spp, int tonemap, double inv_gamma,
@@ -1794,6 +1878,101 @@ int mcrt_intersect_noalloc(mcrt_ctx* c, uint64_t n, const float* o, const float*
     HIP_TRY(c, hipMemcpyAsync(out_obj, dobj, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(out_elem, delem, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(out_t, dt, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+
+namespace {
+uint32_t batch_blocks(const mcrt_ctx* c, uint64_t n) { return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)grid_for(c))); }
+size_t small_lds_bytes(const mcrt_ctx* c) { return (((size_t)c->view.small_words + 3u) & ~size_t(3)) * 4; }
+}
+
+int mcrt_object_intersect(mcrt_ctx* c, uint32_t object_index, uint64_t n, const float* o, const float* d, uint8_t* out_hit, uint32_t* out_elem, float* out_t)
+{
+    int rc = need_scene(c, false);
+    if (rc) return rc;
+    if (object_index >= c->view.nobj) return fail(c, MCRT_ERR_INVALID, "object index outside the scene");
+    if (n == 0) return MCRT_OK;
+    if (!o || !d || !out_hit || !out_elem || !out_t) return fail(c, MCRT_ERR_INVALID, "null buffer");
+    DevBuf<float> dor, ddi, dt;
+    DevBuf<uint8_t> dhit;
+    DevBuf<uint32_t> delem;
+    HIP_TRY(c, hipMalloc(&dor.p, n * 12)); HIP_TRY(c, hipMalloc(&ddi.p, n * 12)); HIP_TRY(c, hipMalloc(&dt.p, n * 4));
+    HIP_TRY(c, hipMalloc(&dhit.p, n)); HIP_TRY(c, hipMalloc(&delem.p, n * 4));
+    HIP_TRY(c, hipMemcpyAsync(dor.p, o, n * 12, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(ddi.p, d, n * 12, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_object_intersect, dim3(batch_blocks(c, n)), dim3(kBlock), small_lds_bytes(c), c->stream, c->view, object_index, n, dor.p, ddi.p, dhit.p, delem.p, dt.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out_hit, dhit.p, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out_elem, delem.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out_t, dt.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+
+int mcrt_surface_normals(mcrt_ctx* c, uint64_t n, const uint32_t* objects, const uint32_t* elems, const float* positions, float* out_normals)
+{
+    int rc = need_scene(c, false);
+    if (rc) return rc;
+    if (n == 0) return MCRT_OK;
+    if (!objects || !elems || !positions || !out_normals) return fail(c, MCRT_ERR_INVALID, "null buffer");
+    for (uint64_t i = 0; i < n; ++i) {
+        if (objects[i] >= c->view.nobj) return fail(c, MCRT_ERR_INVALID, "object index outside the scene");
+        const uint32_t* rec = c->flat.small_img.data() + c->view.off_obj + (size_t)objects[i] * OBJ_STRIDE;
+        if (rec[OBJ_KIND] != (uint32_t)MCRT_OBJECT_SPHERE && elems[i] >= rec[OBJ_TRI_COUNT]) return fail(c, MCRT_ERR_INVALID, "element index outside the mesh");
+    }
+    DevBuf<uint32_t> dob, del;
+    DevBuf<float> dpos, dout;
+    HIP_TRY(c, hipMalloc(&dob.p, n * 4)); HIP_TRY(c, hipMalloc(&del.p, n * 4)); HIP_TRY(c, hipMalloc(&dpos.p, n * 12)); HIP_TRY(c, hipMalloc(&dout.p, n * 12));
+    HIP_TRY(c, hipMemcpyAsync(dob.p, objects, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(del.p, elems, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dpos.p, positions, n * 12, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_surface_normals, dim3(batch_blocks(c, n)), dim3(kBlock), small_lds_bytes(c), c->stream, c->view, n, dob.p, del.p, dpos.p, dout.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out_normals, dout.p, n * 12, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+
+int mcrt_random_surface_points(mcrt_ctx* c, uint32_t object_index, uint64_t n, uint64_t* rng_states, float* out_points)
+{
+    int rc = need_scene(c, false);
+    if (rc) return rc;
+    if (object_index >= c->view.nobj) return fail(c, MCRT_ERR_INVALID, "object index outside the scene");
+    if (n == 0) return MCRT_OK;
+    if (!rng_states || !out_points) return fail(c, MCRT_ERR_INVALID, "null buffer");
+    DevBuf<uint64_t> dst;
+    DevBuf<float> dout;
+    HIP_TRY(c, hipMalloc(&dst.p, n * 16)); HIP_TRY(c, hipMalloc(&dout.p, n * 12));
+    HIP_TRY(c, hipMemcpyAsync(dst.p, rng_states, n * 16, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_surface_points, dim3(batch_blocks(c, n)), dim3(kBlock), small_lds_bytes(c), c->stream, c->view, object_index, n, dst.p, dout.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out_points, dout.p, n * 12, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(rng_states, dst.p, n * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+
+int mcrt_brdf(mcrt_ctx* c, const mcrt_material* material, uint64_t n, const float* incident, const float* reflection, const float* normal, double* out)
+{
+    if (!c) return MCRT_ERR_INVALID;
+    int rc = bind_device(c);
+    if (rc) return rc;
+    if (!material) return fail(c, MCRT_ERR_INVALID, "null material");
+    if (material->diffuse < 0 || material->diffuse > 1) return fail(c, MCRT_ERR_INVALID, "material enum out of range");
+    if (n == 0) return MCRT_OK;
+    if (!incident || !reflection || !normal || !out) return fail(c, MCRT_ERR_INVALID, "null buffer");
+    float on_a, on_b;
+    oren_nayar_terms(material->roughness, on_a, on_b);
+    DevBuf<float> di, dr, dn;
+    DevBuf<double> dout;
+    HIP_TRY(c, hipMalloc(&di.p, n * 12)); HIP_TRY(c, hipMalloc(&dr.p, n * 12)); HIP_TRY(c, hipMalloc(&dn.p, n * 12)); HIP_TRY(c, hipMalloc(&dout.p, n * 8));
+    HIP_TRY(c, hipMemcpyAsync(di.p, incident, n * 12, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dr.p, reflection, n * 12, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dn.p, normal, n * 12, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_brdf, dim3(batch_blocks(c, n)), dim3(kBlock), 0, c->stream, (uint32_t)material->diffuse, material->albedo, on_a, on_b, n, di.p, dr.p, dn.p, dout.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, dout.p, n * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MCRT_OK;
 }

@@ -213,6 +213,16 @@ inline F3 cross3(F3 x, F3 y) { return { x.y * y.z - y.y * x.z, x.z * y.x - y.z *
 inline F3 norm3(F3 v) { float inv = 1.0f / std::sqrt(dot3(v, v)); return { v.x * inv, v.y * inv, v.z * inv }; }
 } // namespace
 
+// A and B of Material::BRDF, source/core/material.h:29-33: functions of the roughness alone (float arithmetic, one rounding per operation)
+void oren_nayar_terms(float roughness, float& A, float& B)
+{
+    volatile float sigma2 = roughness * roughness;
+    volatile float qa = 0.5f * sigma2 / (sigma2 + 0.57f);
+    volatile float qb = 0.45f * sigma2 / (sigma2 + 0.09f);
+    volatile float a = 1.0f - qa;
+    A = a; B = qb;
+}
+
 void camera_look_at(uint32_t width, uint32_t height, float fov_y_degrees, const float position[3], const float look_at[3],
                     const float up[3], mcrt_camera* out)
 {
@@ -430,13 +440,10 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
         w[OBJ_ROUGHNESS] = fbits(o.material.roughness);
         w[OBJ_IOR] = fbits(o.material.refractive_index);
         {
-            // Material::BRDF, source/core/material.h:29-33 (float arithmetic, one rounding per operation)
-            volatile float sigma2 = o.material.roughness * o.material.roughness;
-            volatile float qa = 0.5f * sigma2 / (sigma2 + 0.57f);
-            volatile float qb = 0.45f * sigma2 / (sigma2 + 0.09f);
-            volatile float A = 1.0f - qa;
+            float A, B;
+            oren_nayar_terms(o.material.roughness, A, B);
             w[OBJ_ON_A] = fbits(A);
-            w[OBJ_ON_B] = fbits(qb);
+            w[OBJ_ON_B] = fbits(B);
         }
         for (int a = 0; a < 3; ++a) {
             put_double(out.small_img, v.off_obj + size_t(i) * OBJ_STRIDE + OBJ_COLOR + 2 * a, o.material.color[a]);

@@ -32,6 +32,9 @@ struct FlatScene {
 // Returns MCRT_OK or an MCRT_ERR_* code with `err` set.
 int flatten_scene(const mcrt_scene_desc* scene, const mcrt_accel_params* accel, FlatScene& out, std::string& err, bool build_tree = true);
 
+// Oren-Nayar A and B of Material::BRDF (source/core/material.h:29-33) with the reference's float operations.
+void oren_nayar_terms(float roughness, float& A, float& B);
+
 // Camera::Camera + Camera::SetView (source/core/camera.h:19-34) with glm's operation order.
 void camera_look_at(uint32_t width, uint32_t height, float fov_y_degrees, const float position[3], const float look_at[3],
                     const float up[3], mcrt_camera* out);

@@ -381,8 +381,99 @@ bool Scene::IntersectRay(Ray& ray, RayIntersectionInfo& hitInfo) const
     return true;
 }
 
+// ---- the per-object virtuals, source/objects/object.h:23-29, forwarded to the device
+bool Scene::ObjectIntersects(unsigned int index, vec3 rayOrigin, vec3 rayDirection, unsigned int& elementIndex, float& hitDistance) const
+{
+    if (!prepared) return Fail("Object::Intersects before PrepareForRayTracing");
+    uint8_t hit = 0; uint32_t elem = 0; float t = FLOAT_INFINITY;
+    if (mcrt_object_intersect(ctx, index, 1, &rayOrigin.x, &rayDirection.x, &hit, &elem, &t) != MCRT_OK) return Fail("object_intersect");
+    elementIndex = elem; hitDistance = t;
+    return hit != 0;
+}
+
+bool Scene::ObjectSurfaceNormal(unsigned int index, vec3 location, unsigned int element, vec3& normal) const
+{
+    if (!prepared) return Fail("Object::GetSurfaceNormal before PrepareForRayTracing");
+    const uint32_t ob = index, el = element;
+    return mcrt_surface_normals(ctx, 1, &ob, &el, &location.x, &normal.x) == MCRT_OK || Fail("surface_normals");
+}
+
+bool Scene::ObjectRandomPoint(unsigned int index, UniformRandomGenerator& gen, vec3& point) const
+{
+    if (!prepared) return Fail("Object::GetRandomPointOnSurface before PrepareForRayTracing");
+    return mcrt_random_surface_points(ctx, index, 1, gen.xorseed, &point.x) == MCRT_OK || Fail("random_surface_points");
+}
+
+static bool Orphan(const char* what)
+{
+    std::fprintf(stderr, "mcrt: %s: the object was not created by Scene::CreateObject\n", what);
+    return false;
+}
+
+bool Object::Intersects(vec3 rayOrigin, vec3 rayDirection, RayIntersectionInfo& hitInfo)
+{
+    unsigned int element = 0;
+    float distance = FLOAT_INFINITY;
+    const bool hit = scene ? scene->ObjectIntersects(sceneIndex, rayOrigin, rayDirection, element, distance) : Orphan("Object::Intersects");
+    if (hit) { hitInfo.object = this; hitInfo.elementIndex = element; hitInfo.hitDistance = distance; }
+    // a missed sphere leaves hitInfo as it was (source/objects/sphere.h:18-45), a missed mesh resets it (source/objects/mesh.cpp:14,36)
+    else if (Kind() != MCRT_OBJECT_SPHERE) hitInfo.Reset();
+    return hit;
+}
+
+vec3 Object::GetSurfaceNormal(vec3 location, unsigned int index)
+{
+    vec3 n{ 0.0f };
+    if (scene) scene->ObjectSurfaceNormal(sceneIndex, location, index, n); else Orphan("Object::GetSurfaceNormal");
+    return n;
+}
+
+vec3 Object::GetRandomPointOnSurface(UniformRandomGenerator& gen)
+{
+    vec3 p = position;
+    if (scene) scene->ObjectRandomPoint(sceneIndex, gen, p); else Orphan("Object::GetRandomPointOnSurface");
+    return p;
+}
+
+// ---- Material::BRDF, source/core/material.h:24-53
+namespace {
+int g_materialDevice = 0;
+mcrt_ctx* MaterialContext()
+{
+    static mcrt_ctx* ctx = nullptr;
+    static int ctxDevice = -1;
+    if (ctx && ctxDevice != g_materialDevice) { mcrt_destroy(ctx); ctx = nullptr; }
+    if (!ctx) {
+        if (mcrt_create(g_materialDevice, &ctx) != MCRT_OK) {
+            std::fprintf(stderr, "mcrt: Material::BRDF: %s\n", mcrt_last_error(nullptr));
+            ctx = nullptr;
+        }
+        ctxDevice = g_materialDevice;
+    }
+    return ctx;
+}
+} // namespace
+
+void MaterialDevice(int deviceId) { g_materialDevice = deviceId; }
+
+double Material::BRDF(vec3& incident, vec3& reflection, vec3& normal)
+{
+    mcrt_ctx* c = MaterialContext();
+    if (!c) return 0.0;
+    mcrt_material m;
+    std::memset(&m, 0, sizeof m);
+    m.diffuse = int32_t(diffuse); m.surface = int32_t(type);
+    m.albedo = albedo; m.roughness = roughness; m.refractive_index = refractiveIndex;
+    double out = 0.0;
+    if (mcrt_brdf(c, &m, 1, &incident.x, &reflection.x, &normal.x, &out) != MCRT_OK) {
+        std::fprintf(stderr, "mcrt: Material::BRDF: %s\n", mcrt_last_error(c));
+        return 0.0;
+    }
+    return out;
+}
+
 // source/scene.cpp:82-92
-ColorDbl Scene::TraceUnlit(Ray ray)
+ColorDbl Scene::TraceUnlit(Ray ray) const
 {
     RayIntersectionInfo hitInfo;
     if (IntersectRay(ray, hitInfo)) return hitInfo.object->material.color;
@@ -771,6 +862,61 @@ int mcrt_host_take_screenshot(const char* filename, const uint8_t* bgra8, unsign
     const std::string name = TakeScreenshot(filename, image, width, height);
     if (out_name && out_cap) { std::strncpy(out_name, name.c_str(), out_cap - 1); out_name[out_cap - 1] = 0; }
     return name.empty() ? 1 : 0;
+}
+
+// Object::Intersects and GetSurfaceNormal through the virtual interface, one call per ray (test hook): object `index` of the scene
+int mcrt_host_object_intersects(void* scene, unsigned index, uint64_t n, const float* o, const float* d, uint8_t* out_hit, uint32_t* out_elem, float* out_t,
+                                float* out_normal)
+{
+    Scene* s = static_cast<Scene*>(scene);
+    if (index >= s->ObjectCount()) return 1;
+    Object* ob = s->GetObject(index);
+    for (uint64_t i = 0; i < n; ++i) {
+        RayIntersectionInfo info;
+        const vec3 ro(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        const bool hit = ob->Intersects(ro, rd, info);
+        if (hit != (info.object == ob)) return 2;
+        out_hit[i] = hit ? 1 : 0; out_elem[i] = info.elementIndex; out_t[i] = info.hitDistance;
+        vec3 nrm{ 0.0f };
+        if (hit) nrm = ob->GetSurfaceNormal(ro + rd * info.hitDistance, info.elementIndex);
+        out_normal[3 * i] = nrm.x; out_normal[3 * i + 1] = nrm.y; out_normal[3 * i + 2] = nrm.z;
+    }
+    return 0;
+}
+
+// Object::GetRandomPointOnSurface through the virtual interface (test hook): one generator, n consecutive points; the final state is returned
+int mcrt_host_object_random_points(void* scene, unsigned index, uint64_t n, uint64_t state[2], float* out)
+{
+    Scene* s = static_cast<Scene*>(scene);
+    if (index >= s->ObjectCount()) return 1;
+    UniformRandomGenerator g(state[0], state[1]);
+    for (uint64_t i = 0; i < n; ++i) {
+        const vec3 p = s->GetObject(index)->GetRandomPointOnSurface(g);
+        out[3 * i] = p.x; out[3 * i + 1] = p.y; out[3 * i + 2] = p.z;
+    }
+    state[0] = g.xorseed[0]; state[1] = g.xorseed[1];
+    return 0;
+}
+
+// Material::BRDF (test hook)
+void mcrt_host_material_brdf(int diffuse, float albedo, float roughness, uint64_t n, const float* inc, const float* refl, const float* nrm, double* out)
+{
+    Material m;
+    m.diffuse = DiffuseType(diffuse); m.albedo = albedo; m.roughness = roughness;
+    for (uint64_t i = 0; i < n; ++i) {
+        vec3 a(inc[3 * i], inc[3 * i + 1], inc[3 * i + 2]), b(refl[3 * i], refl[3 * i + 1], refl[3 * i + 2]), c(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]);
+        out[i] = m.BRDF(a, b, c);
+    }
+}
+
+// const Scene::TraceUnlit (source/scene.h:43) through a const reference (test hook)
+void mcrt_host_trace_unlit(void* scene, uint64_t n, const float* o, const float* d, double* out)
+{
+    const Scene& s = *static_cast<Scene*>(scene);
+    for (uint64_t i = 0; i < n; ++i) {
+        const ColorDbl c = s.TraceUnlit(Ray(vec3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), vec3(d[3 * i], d[3 * i + 1], d[3 * i + 2])));
+        out[3 * i] = c.r; out[3 * i + 1] = c.g; out[3 * i + 2] = c.b;
+    }
 }
 
 int mcrt_host_scene_flatten(void* scene, mcrt_scene_desc* out) { return static_cast<Scene*>(scene)->Flatten(*out) ? 0 : 1; }

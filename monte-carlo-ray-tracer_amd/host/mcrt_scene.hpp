@@ -41,7 +41,12 @@ struct Material {
     float albedo = 1.0f;
     float roughness = 1.0f;
     float refractiveIndex = 1.52f;
+    // source/core/material.h:24-53.  Evaluated on the device (mcrt_brdf, the kernels' own BRDF code) through the process-wide
+    // context of MaterialDevice(); 0.0 and a message on stderr where there is no GPU.
+    double BRDF(vec3& incident, vec3& reflection, vec3& normal);
 };
+// The GPU Material::BRDF runs on (a Material belongs to no scene): device index for the process-wide context, default 0.
+void MaterialDevice(int deviceId);
 
 struct Ray {
     vec3 origin;
@@ -88,7 +93,12 @@ public:
     float RandomFloat(float min, float max) { return min + (max - min) * float(RandomDouble()); }
 };
 
+class Scene;
 class Object {
+protected:
+    friend class Scene;
+    Scene* scene = nullptr;            // the scene that created the object (Scene::CreateObject) and its place in the object order
+    unsigned int sceneIndex = 0;
 public:
     vec3 position;
     Material material;
@@ -96,7 +106,15 @@ public:
     AABB aabb;
     Object() = default;
     virtual ~Object() = default;
+    // The three ray-arithmetic virtuals of source/objects/object.h:23-29.  They run on the device against the scene image
+    // uploaded by the last Scene::PrepareForRayTracing (mcrt_object_intersect / mcrt_surface_normals /
+    // mcrt_random_surface_points): an object edited since then answers with its old geometry, as the reference's objects
+    // answer with a stale AABB until PrepareForRayTracing has run.  An object that belongs to no prepared scene reports
+    // a miss / a zero vector and a message on stderr.
+    virtual bool Intersects(vec3 rayOrigin, vec3 rayDirection, RayIntersectionInfo& hitInfo);
+    virtual vec3 GetSurfaceNormal(vec3 location, unsigned int index);
     virtual bool IsLight() { return false; }
+    virtual vec3 GetRandomPointOnSurface(UniformRandomGenerator& gen);
     virtual double PDF() { return 1.0 / area; }
     virtual void UpdateAABB() {}
     virtual int Kind() const = 0;                                  // MCRT_OBJECT_*
@@ -172,7 +190,6 @@ public:
     const mcrt_camera& Description() const { return view; }
 };
 
-class Scene;
 // Scene::octree: the entry point name and knobs of the reference's Octree; the structure itself is the
 // flat per-primitive octree built inside mcrt_upload_scene.
 class Octree {
@@ -214,10 +231,16 @@ public:
     template <class T> T* CreateObject()
     {
         T* newObject = new T();
+        newObject->scene = this;
+        newObject->sceneIndex = (unsigned int)objects.size();
         objects.push_back(newObject);
         prepared = false;
         return newObject;
     }
+
+    // objects in creation order - the order of the nearest-hit tie-break (the reference keeps `objects` protected, source/scene.h:18-20)
+    unsigned int ObjectCount() const { return (unsigned int)objects.size(); }
+    Object* GetObject(unsigned int index) { return objects[index]; }
 
     void UseDevice(int deviceId) { device = deviceId; }
     mcrt_ctx* Context() { return EnsureContext() ? ctx : nullptr; }
@@ -228,7 +251,7 @@ public:
     bool Flatten(mcrt_scene_desc& out);
 
     bool IntersectRay(Ray& ray, RayIntersectionInfo& hitInfo) const;      // source/scene.h:41
-    ColorDbl TraceUnlit(Ray ray);
+    ColorDbl TraceUnlit(Ray ray) const;                                    // source/scene.h:43
     double MaxImportance(ColorDbl& importance)
     {
         double yz = importance.g < importance.b ? importance.b : importance.g;
@@ -262,6 +285,11 @@ public:
     void SetSampleCount(Camera& camera, uint64_t samples) { camera.pixels.rays = samples; }
 
     virtual void MoveCameraToRecommendedPosition(Camera& camera);
+
+    // what Object::Intersects / GetSurfaceNormal / GetRandomPointOnSurface forward to (object `index` of the uploaded image)
+    bool ObjectIntersects(unsigned int index, vec3 rayOrigin, vec3 rayDirection, unsigned int& elementIndex, float& hitDistance) const;
+    bool ObjectSurfaceNormal(unsigned int index, vec3 location, unsigned int element, vec3& normal) const;
+    bool ObjectRandomPoint(unsigned int index, UniformRandomGenerator& gen, vec3& point) const;
 };
 
 // source/opengl/screenshot.cpp:13-76 without the window: the image is the resolved BGRA8 buffer (Scene::Resolve, top row first)

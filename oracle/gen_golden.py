@@ -277,6 +277,28 @@ def hits_and_samples(R, name, scene, flat, cam, rng, n_samples):
          camera=abi.camera_to_numpy(cam))
 
 
+def object_api_fixture(R, name, scene, flat, rng, n_rays=1500, n_points=600):
+    """Round 3: every object of the scene ALONE through the reference's virtual interface (source/objects/object.h:23-29):
+    Intersects on rays taken from the scene's hit fixture (primary, secondary, adversarial and pad-margin rays alike), the surface
+    normal at every hit, and GetRandomPointOnSurface from seeded generator states."""
+    g = np.load(os.path.join(OUT, f"hits_{name}.npz"))
+    pick = rng.choice(len(g["origins"]), n_rays, replace=False)
+    o, d = np.ascontiguousarray(g["origins"][pick]), np.ascontiguousarray(g["dirs"][pick])
+    nobj = len(flat.objects)
+    hit = np.zeros((nobj, n_rays), bool); elem = np.zeros((nobj, n_rays), np.uint32); t = np.zeros((nobj, n_rays), F)
+    nrm = np.zeros((nobj, n_rays, 3), F)
+    states = rng.integers(1, 2 ** 63, size=(n_points, 2)).astype(np.uint64)
+    pts = np.zeros((nobj, n_points, 3), F); st_out = np.zeros((nobj, n_points, 2), np.uint64)
+    for i in range(nobj):
+        hit[i], elem[i], t[i] = R.object_intersects(scene, i, o, d)
+        p = (o + d * t[i][:, None]).astype(F)
+        nrm[i] = R.surface_normal(scene, np.full(n_rays, i, np.int32), elem[i], p)
+        nrm[i][~hit[i]] = 0
+        pts[i], st_out[i] = R.object_random_points(scene, i, states)
+    assert hit.any(axis=1).sum() >= nobj - 1            # (a zero-radius point light is never hit)
+    save(f"object_api_{name}.npz", origins=o, dirs=d, hit=hit, elem=elem, t=t, normal=nrm, states=states, points=pts, states_out=st_out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if not po.Ref.available():
@@ -358,6 +380,10 @@ def main():
     f4d, l4 = R.dump(sc4)
     scene_fixture(R, "config4_2k", sc4, f4d, l4)
     hits_and_samples(R, "config4_2k", sc4, f4d, cam512, rng, 1024)
+
+    print("F9 the per-object virtuals (Object::Intersects / GetSurfaceNormal / GetRandomPointOnSurface of every object alone)")
+    for name, sc_h, fl in (("cornell", cornell, flat), ("cornell_point", point, pflat), ("cornell_sphere_light", ssc, sflat2), ("hexagon", hexa, hflat)):
+        object_api_fixture(R, name, sc_h, fl, np.random.default_rng([20261203, len(name)]))
 
     print("F6 images (accumulator sums)")
     cam128 = R.camera(128, 128, 90.0, (0, 0, 5), (0, 0, 0))

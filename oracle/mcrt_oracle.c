@@ -958,6 +958,37 @@ static inline v3 light_point(const mcrt_object* L, rng_t* g, const mathfn* mf)
     return pos;
 }
 
+/* Object::GetRandomPointOnSurface for one object, one point per generator state (advanced state written back) */
+ORC_EXPORT void orc_object_random_points(const orc_scene* S, uint32_t index, uint64_t n, uint64_t* states, int portable_math, float* out)
+{
+    const mathfn* mf = portable_math ? &MATH_PORTABLE : &MATH_LIBM;
+    for (uint64_t i = 0; i < n; ++i) {
+        rng_t g = { { states[2 * i], states[2 * i + 1] } };
+        st3(out + 3 * i, light_point(&S->obj[index], &g, mf));
+        states[2 * i] = g.s[0]; states[2 * i + 1] = g.s[1];
+    }
+}
+
+/* Object::Intersects of ONE object (source/objects/object.h:23): SphereObject::Intersects, source/objects/sphere.h:16-52, or
+ * TriangleMesh::Intersects, source/objects/mesh.cpp:9-41; hitInfo starts reset (source/core/ray.h:17-29) */
+ORC_EXPORT void orc_object_intersects(const orc_scene* S, uint32_t index, uint64_t n, const float* o, const float* d, uint8_t* out_hit,
+                                      uint32_t* out_elem, float* out_t)
+{
+    const mcrt_object* ob = &S->obj[index];
+    for (uint64_t i = 0; i < n; ++i) {
+        v3 ro = ld3(o + 3 * i), rd = ld3(d + 3 * i);
+        int hit = 0; uint32_t elem = 0; float t = FLT_MAX;
+        if (ob->kind == MCRT_OBJECT_SPHERE) { float ts; if (sphere_hit(ob, ro, rd, &ts)) { hit = 1; t = ts; } }
+        else if (aabb_hit(ob->aabb_min, ob->aabb_max, ro, rd)) {
+            float nearest = FLT_MAX, hitDistance = FLT_MAX;
+            for (uint32_t k = 0; k < ob->triangle_count; ++k)
+                if (tri_hit(&S->tri[ob->first_triangle + k], ro, rd, &hitDistance) && hitDistance < nearest) { nearest = hitDistance; elem = k; }
+            if (nearest < FLT_MAX) { hit = 1; t = nearest; } else elem = 0;
+        }
+        out_hit[i] = (uint8_t)hit; out_elem[i] = elem; out_t[i] = t;
+    }
+}
+
 /* ------------------------------------------------------------------ TraceRay
  * Scene::TraceRay, source/scene.cpp:94-234.  `pending` counts reflect
  * branches that are waiting while a refract branch runs (the refract operand

@@ -234,6 +234,21 @@ class Oracle:
         self.lib.orc_hemisphere(C.c_uint64(len(nn)), _p(nn, C.c_float), _p(st, C.c_uint64), C.c_int(int(portable_math)), _p(d, C.c_float), _p(c, C.c_float))
         return d, c
 
+    def object_intersects(self, scene, index, origins, dirs):
+        """Object::Intersects of one object: (hit, elementIndex, hitDistance) as the call leaves a fresh RayIntersectionInfo."""
+        o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)
+        n = len(o)
+        hit = np.zeros(n, np.uint8); elem = np.zeros(n, np.uint32); t = np.zeros(n, np.float32)
+        self.lib.orc_object_intersects(C.c_void_p(scene.h), C.c_uint32(index), C.c_uint64(n), _p(o, C.c_float), _p(d, C.c_float), _p(hit, C.c_uint8), _p(elem, C.c_uint32), _p(t, C.c_float))
+        return hit.astype(bool), elem, t
+
+    def object_random_points(self, scene, index, states, portable_math=False):
+        """Object::GetRandomPointOnSurface, one point per generator state: (points, advanced states)."""
+        st = np.array(states, dtype=np.uint64).reshape(-1, 2).copy()
+        out = np.zeros((len(st), 3), np.float32)
+        self.lib.orc_object_random_points(C.c_void_p(scene.h), C.c_uint32(index), C.c_uint64(len(st)), _p(st, C.c_uint64), C.c_int(int(portable_math)), _p(out, C.c_float))
+        return out, st
+
     def surface_normal(self, scene, obj, elem, points):
         obj = np.ascontiguousarray(obj, np.int32); elem = _u32(elem); pts = _f32(points).reshape(-1, 3)
         out = np.zeros((len(obj), 3), np.float32)
@@ -428,6 +443,20 @@ class Ref:
         d = np.zeros((len(nn), 3), np.float32); c = np.zeros(len(nn), np.float32)
         self.lib.ref_hemisphere(C.c_uint64(len(nn)), _p(nn, C.c_float), _p(st, C.c_uint64), _p(d, C.c_float), _p(c, C.c_float))
         return d, c
+
+    def object_intersects(self, scene, index, origins, dirs):
+        o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)
+        n = len(o)
+        hit = np.zeros(n, np.uint8); elem = np.zeros(n, np.uint32); t = np.zeros(n, np.float32)
+        self.lib.ref_object_intersects(C.c_void_p(scene.h), C.c_uint32(index), C.c_uint64(n), _p(o, C.c_float), _p(d, C.c_float), _p(hit, C.c_uint8), _p(elem, C.c_uint32), _p(t, C.c_float))
+        return hit.astype(bool), elem, t
+
+    def object_random_points(self, scene, index, states, portable_math=False):
+        assert not portable_math
+        st = np.array(states, dtype=np.uint64).reshape(-1, 2).copy()
+        out = np.zeros((len(st), 3), np.float32)
+        self.lib.ref_object_random_points(C.c_void_p(scene.h), C.c_uint32(index), C.c_uint64(len(st)), _p(st, C.c_uint64), _p(out, C.c_float))
+        return out, st
 
     def surface_normal(self, scene, obj, elem, points):
         obj = np.ascontiguousarray(obj, np.int32); elem = _u32(elem); pts = _f32(points).reshape(-1, 3)

@@ -30,6 +30,7 @@ namespace {
 /* UniformRandomGenerator::xorseed is protected (source/core/randomization.h:15-16). */
 struct SeedableRng : UniformRandomGenerator {
     void Seed(uint64_t a, uint64_t b) { xorseed[0] = a; xorseed[1] = b; }
+    void State(uint64_t out[2]) const { out[0] = xorseed[0]; out[1] = xorseed[1]; }
 };
 
 /* Scene::objects / lights / RandomHemisphereRay are protected (source/scene.h:18-22). */
@@ -344,6 +345,34 @@ void ref_surface_normal(void* h, uint64_t n, const int32_t* obj, const uint32_t*
     Scene& s = *static_cast<RefScene*>(h)->scene;
     auto& objs = SceneAccess::Objects(s);
     for (uint64_t i = 0; i < n; ++i) Put3(out + 3 * i, objs[size_t(obj[i])]->GetSurfaceNormal(Get3(points + 3 * i), elem[i]));
+}
+
+/* Object::Intersects of ONE object through the virtual interface (source/objects/object.h:23): the bool it returns and
+ * hitInfo as the call leaves it, starting from a fresh RayIntersectionInfo (source/core/ray.h:17-29) */
+void ref_object_intersects(void* h, uint32_t index, uint64_t n, const float* o, const float* d, uint8_t* out_hit, uint32_t* out_elem, float* out_t)
+{
+    Scene& s = *static_cast<RefScene*>(h)->scene;
+    Object* ob = SceneAccess::Objects(s)[index];
+    for (uint64_t i = 0; i < n; ++i) {
+        RayIntersectionInfo info;
+        out_hit[i] = ob->Intersects(Get3(o + 3 * i), Get3(d + 3 * i), info) ? 1 : 0;
+        out_elem[i] = info.elementIndex;
+        out_t[i] = info.hitDistance;
+    }
+}
+
+/* Object::GetRandomPointOnSurface (source/objects/object.h:26-29, light.h:47-53, sphere.h:59-69): one point per generator
+ * state, the advanced state written back */
+void ref_object_random_points(void* h, uint32_t index, uint64_t n, uint64_t* states, float* out)
+{
+    Scene& s = *static_cast<RefScene*>(h)->scene;
+    Object* ob = SceneAccess::Objects(s)[index];
+    SeedableRng g;
+    for (uint64_t i = 0; i < n; ++i) {
+        g.Seed(states[2 * i], states[2 * i + 1]);
+        Put3(out + 3 * i, ob->GetRandomPointOnSurface(g));
+        g.State(states + 2 * i);
+    }
 }
 
 /* ----------------------------------------------------------------- tracing */

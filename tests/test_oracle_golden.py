@@ -178,3 +178,26 @@ def test_oracle_against_live_reference_on_random_scenes(oracle, ref, scene_of, s
     rb = oracle.trace_samples(oracle.scene(flat), cam_o, px, sm, 4242, 100)
     same = (ra.view(np.uint64) == rb.view(np.uint64)).all(axis=1) | (np.isnan(ra).any(axis=1) & np.isnan(rb).any(axis=1))
     assert same.all(), f"{(~same).sum()} of {len(same)} samples differ"
+
+
+@pytest.mark.parametrize("name", ["cornell", "cornell_point", "cornell_sphere_light", "hexagon"])
+def test_per_object_virtuals_bit_exact(oracle, scene_of, golden, name):
+    """F9: Object::Intersects / GetSurfaceNormal / GetRandomPointOnSurface of every object alone, as the reference's virtuals answer."""
+    g = golden(f"object_api_{name}.npz")
+    flat = scene_of(name)
+    sc = oracle.scene(flat)
+    for i in range(len(flat.objects)):
+        hit, elem, t = oracle.object_intersects(sc, i, g["origins"], g["dirs"])
+        assert np.array_equal(hit, g["hit"][i]) and np.array_equal(elem, g["elem"][i]) and np.array_equal(t.view(np.uint32), g["t"][i].view(np.uint32))
+        p = (g["origins"] + g["dirs"] * t[:, None]).astype(np.float32)
+        n = oracle.surface_normal(sc, np.full(len(p), i, np.int32), elem, p)
+        assert np.array_equal(n[hit].view(np.uint32), g["normal"][i][hit].view(np.uint32))
+        pts, st = oracle.object_random_points(sc, i, g["states"])
+        assert np.array_equal(pts.view(np.uint32), g["points"][i].view(np.uint32)) and np.array_equal(st, g["states_out"][i])
+    # the loop of Scene::IntersectRay (source/scene.cpp:62-80) rebuilt from the per-object answers gives the scene-level hits
+    best_t = np.full(len(g["origins"]), np.finfo(np.float32).max, np.float32); best_o = np.full(len(best_t), -1, np.int32)
+    for i in range(len(flat.objects)):
+        better = g["hit"][i] & (g["t"][i] < best_t)
+        best_t[better] = g["t"][i][better]; best_o[better] = i
+    so, _, st_ = oracle.intersect(sc, g["origins"], g["dirs"])
+    assert np.array_equal(best_o, so) and np.array_equal(best_t, st_)
