@@ -5,6 +5,7 @@
 #include "mcrt_scene.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -75,6 +76,87 @@ void TriangleMesh::UpdateAABB()
 // Replaces TriangleMesh::LoadMesh (source/objects/mesh.cpp:70-105), which ignores the face indices
 // (SURVEY.md 0.4).  Reads `v` and `f` records; faces are fan-triangulated (a,b,c),(a,c,d),... in file
 // order; vertices are offset by `position` as the reference does.  Prints and returns false on error.
+// ---- polygon triangulation as the reference's OBJ reader does it (source/helpers/OBJ_Loader.h:820-985, "OBJL": the library
+// TriangleMesh::LoadMesh reads files with, source/objects/mesh.cpp:70-80), so that a face with more than three corners becomes
+// the triangles the reference's loader would get.  The procedure, quirks included (pinned by tests/golden/obj_triangulation.npz,
+// which OBJL itself produced):
+//   - ear clipping from the front of the corner list: the first corner whose triangle (previous, corner, next) holds no other
+//     corner of the face is cut off, and the search starts over; with four corners left the face is closed with (previous,
+//     corner, next) and (previous, next, the fourth);
+//   - a triangle's corners are always emitted in ASCENDING position within the face (OBJL matches them back by position);
+//   - the containment test only works for faces whose plane passes through the coordinate origin: OBJL projects the corner's
+//     POSITION VECTOR onto the triangle's normal and asks for an exact zero (OBJ_Loader.h:291-301).  Everywhere else nothing is
+//     ever "inside", and an n-gon comes out as (k, k+1, n-1), k = 0 .. n-3 - for a quad (0,1,3), (1,2,3);
+//   - its angle test (`angle <= 0 && angle >= 180`, :931-933) can never hold and is left out.
+namespace {
+struct P3 { float x, y, z; };
+inline bool same(const P3& a, const P3& b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+inline P3 sub(const P3& a, const P3& b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+inline P3 crossp(const P3& a, const P3& b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+inline float dotp(const P3& a, const P3& b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+inline float length(const P3& a) { return sqrtf(powf(a.x, 2) + powf(a.y, 2) + powf(a.z, 2)); }      // OBJL's MagnitudeV3, :217-220
+// both on the same side of the line a-b (OBJ_Loader.h:257-266)
+inline bool sameSide(const P3& p1, const P3& p2, const P3& a, const P3& b) { return dotp(crossp(sub(b, a), sub(p1, a)), crossp(sub(b, a), sub(p2, a))) >= 0; }
+// OBJ_Loader.h:280-302
+bool inTriangle(const P3& point, const P3& t1, const P3& t2, const P3& t3)
+{
+    if (!(sameSide(point, t1, t2, t3) && sameSide(point, t2, t1, t3) && sameSide(point, t3, t1, t2))) return false;
+    const P3 n = crossp(sub(t2, t1), sub(t3, t1));
+    const float len = length(n);
+    const P3 bn = { n.x / len, n.y / len, n.z / len };
+    const float along = dotp(point, bn);
+    const P3 proj = { bn.x * along, bn.y * along, bn.z * along };
+    return length(proj) == 0;
+}
+// every corner of `face` whose position equals one of the three, in face order
+void emit(const std::vector<P3>& face, size_t upTo, const P3& a, const P3& b, const P3& c, std::vector<unsigned>& out)
+{
+    for (size_t j = 0; j < upTo; ++j) {
+        if (same(face[j], a)) out.push_back(unsigned(j));
+        if (same(face[j], b)) out.push_back(unsigned(j));
+        if (same(face[j], c)) out.push_back(unsigned(j));
+    }
+}
+void triangulate(const std::vector<P3>& face, std::vector<unsigned>& out)
+{
+    if (face.size() < 3) return;
+    if (face.size() == 3) { out.push_back(0); out.push_back(1); out.push_back(2); return; }
+    std::vector<P3> left = face;
+    for (;;) {
+        for (int i = 0; i < int(left.size()); ++i) {
+            const P3 prev = left[i == 0 ? left.size() - 1 : size_t(i) - 1], cur = left[size_t(i)], next = left[size_t(i) + 1 == left.size() ? 0 : size_t(i) + 1];
+            if (left.size() == 3) {
+                emit(face, left.size(), cur, prev, next, out);           // (OBJL scans only the first three corners of the face here, :876-884)
+                left.clear();
+                break;
+            }
+            if (left.size() == 4) {
+                emit(face, face.size(), cur, prev, next, out);
+                P3 fourth = { 0, 0, 0 };
+                for (const P3& q : left)
+                    if (!same(q, cur) && !same(q, prev) && !same(q, next)) { fourth = q; break; }
+                emit(face, face.size(), prev, next, fourth, out);
+                left.clear();
+                break;
+            }
+            bool holds = false;
+            for (const P3& q : face)
+                if (inTriangle(q, prev, cur, next) && !same(q, prev) && !same(q, cur) && !same(q, next)) { holds = true; break; }
+            if (holds) continue;
+            emit(face, face.size(), cur, prev, next, out);
+            for (size_t j = 0; j < left.size(); ++j)
+                if (same(left[j], cur)) { left.erase(left.begin() + long(j)); break; }
+            i = -1;
+        }
+        if (out.empty() || left.empty()) break;
+    }
+}
+} // namespace
+
+// The reference's LoadMesh (source/objects/mesh.cpp:70-105) hands the file to OBJL and then builds its triangles from
+// Vertices[k..k+2] in a sliding window, ignoring Indices and reading past the end.  This one builds them from
+// the indices: v / f records (f corners as "v", "v/vt", "v/vt/vn", "v//vn", negative = relative to the end, as OBJL resolves
+// them, :382-390), faces triangulated as OBJL triangulates them (above), every vertex offset by `position` (mesh.cpp:98-100).
 bool TriangleMesh::LoadMesh(std::string path)
 {
     std::ifstream in(path);
@@ -82,7 +164,7 @@ bool TriangleMesh::LoadMesh(std::string path)
         std::printf("Failed to load mesh from path: %s\r\n", path.c_str());
         return false;
     }
-    std::vector<vec3> verts;
+    std::vector<P3> verts;
     std::string line;
     size_t before = triangles.size();
     while (std::getline(in, line)) {
@@ -91,18 +173,24 @@ bool TriangleMesh::LoadMesh(std::string path)
         ls >> tag;
         if (tag == "v") {
             float x, y, z;
-            if (ls >> x >> y >> z) verts.push_back(vec3(x, y, z));
+            if (ls >> x >> y >> z) verts.push_back({ x, y, z });
         } else if (tag == "f") {
-            std::vector<long> idx;
+            std::vector<P3> face;
             std::string tok;
+            bool ok = true;
             while (ls >> tok) {
-                long i = std::strtol(tok.c_str(), nullptr, 10);        // "v", "v/vt", "v/vt/vn", "v//vn"
+                long i = std::strtol(tok.c_str(), nullptr, 10);
                 if (i < 0) i = long(verts.size()) + i + 1;               // relative indices
-                if (i < 1 || i > long(verts.size())) { idx.clear(); break; }
-                idx.push_back(i - 1);
+                if (i < 1 || i > long(verts.size())) { ok = false; break; }
+                face.push_back(verts[size_t(i - 1)]);
             }
-            for (size_t k = 1; k + 1 < idx.size(); ++k)
-                triangles.push_back(Triangle{ verts[size_t(idx[0])] + position, verts[size_t(idx[k])] + position, verts[size_t(idx[k + 1])] + position });
+            if (!ok) continue;
+            std::vector<unsigned> idx;
+            triangulate(face, idx);
+            for (size_t k = 0; k + 2 < idx.size(); k += 3) {
+                const P3 &a = face[idx[k]], &b = face[idx[k + 1]], &c = face[idx[k + 2]];
+                triangles.push_back(Triangle{ vec3(a.x, a.y, a.z) + position, vec3(b.x, b.y, b.z) + position, vec3(c.x, c.y, c.z) + position });
+            }
         }
     }
     std::printf("Loaded obj: %s (%zu triangles)\r\n", path.c_str(), triangles.size() - before);

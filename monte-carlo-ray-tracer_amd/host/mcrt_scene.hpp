@@ -132,7 +132,7 @@ public:
     std::vector<Triangle> triangles;
     void AddQuad(vec3 p1, vec3 p2, vec3 p3, vec3 p4);              // ccw with respect to the normal
     void UpdateAABB() override;
-    // Index-correct OBJ reader (v / f records; quads and n-gons fan-triangulated), offset by `position`.
+    // Index-correct OBJ reader (v / f records; faces triangulated the way the reference's OBJ library does it), offset by `position`.
     bool LoadMesh(std::string path);
     int Kind() const override { return MCRT_OBJECT_MESH; }
 };

@@ -76,8 +76,10 @@ def add_mesh(flat, tris, position=(0.0, 0.0, 0.0), mat=None):
 # --------------------------------------------------------------------- config 2
 # Geometry of the three stacked cubes of the reference's binaries/box_stack.obj
 # asset, restated from its facts (24 vertices, 18 quads); faces triangulated by
-# their indices as (a,b,c),(a,c,d) - not by the broken sliding window of
-# TriangleMesh::LoadMesh (source/objects/mesh.cpp:92-103).
+# their indices the way the reference's OBJ library splits a quad - (a,b,d),
+# (b,c,d), source/helpers/OBJ_Loader.h:890-928; tests/golden/obj_triangulation.npz
+# holds that library's own output for these faces - not by the broken sliding
+# window of TriangleMesh::LoadMesh (source/objects/mesh.cpp:92-103).
 _BOX_STACK_FACES = ((2, 4, 3, 1), (4, 8, 7, 3), (8, 6, 5, 7), (6, 2, 1, 5), (1, 3, 7, 5), (6, 8, 4, 2))
 
 
@@ -85,22 +87,39 @@ def _axis_cube(h, y0, y1):
     return [(h, y0, h), (h, y1, h), (-h, y0, h), (-h, y1, h), (h, y0, -h), (h, y1, -h), (-h, y0, -h), (-h, y1, -h)]
 
 
-def box_stack_triangles(offset=(0.0, 0.0, 0.0)):
+def _box_stack_cubes():
     r = 0.754531
-    cubes = [
+    return [
         _axis_cube(0.234105, 2.076805, 2.545015),
         [(0.0, 1.004430, r), (0.0, 2.071499, r), (-r, 1.004430, 0.0), (-r, 2.071499, 0.0), (r, 1.004430, -0.0), (r, 2.071499, -0.0),
          (-0.0, 1.004430, -r), (-0.0, 2.071499, -r)],
         [(-1.0, -1.0, 1.0), (-1.0, 1.0, 1.0), (-1.0, -1.0, -1.0), (-1.0, 1.0, -1.0), (1.0, -1.0, 1.0), (1.0, 1.0, 1.0), (1.0, -1.0, -1.0),
          (1.0, 1.0, -1.0)],
     ]
+
+
+def box_stack_obj_text():
+    """The three cubes as an OBJ file: 24 `v` records, 18 quad `f` records with 1-based indices (the asset's shape)."""
+    lines = ["# three stacked cubes", "o stack"]
+    faces = []
+    for k, verts in enumerate(_box_stack_cubes()):
+        for v in verts:
+            lines.append("v %.9g %.9g %.9g" % tuple(float(np.float32(x)) for x in v))
+        for f in _BOX_STACK_FACES:
+            faces.append("f " + " ".join(str(8 * k + i) for i in f))
+    return "\n".join(lines + faces) + "\n"
+
+
+def box_stack_triangles(offset=(0.0, 0.0, 0.0)):
+    cubes = _box_stack_cubes()
     off = np.asarray(offset, F)
     a, b, c = [], [], []
     for verts in cubes:
         v = np.asarray(verts, F) + off
         for f in _BOX_STACK_FACES:
             p = [v[i - 1] for i in f]
-            a += [p[0], p[0]]; b += [p[1], p[2]]; c += [p[2], p[3]]
+            # a quad as the reference's OBJ library splits it (source/helpers/OBJ_Loader.h:890-928): (0, 1, 3), (1, 2, 3)
+            a += [p[0], p[1]]; b += [p[1], p[2]]; c += [p[3], p[3]]
     return make_triangles(a, b, c)
 
 

@@ -299,6 +299,65 @@ def object_api_fixture(R, name, scene, flat, rng, n_rays=1500, n_points=600):
     save(f"object_api_{name}.npz", origins=o, dirs=d, hit=hit, elem=elem, t=t, normal=nrm, states=states, points=pts, states_out=st_out)
 
 
+OBJ_TEXT = """# faces for TriangleMesh::LoadMesh: what the reference's OBJ library (OBJL) makes of them
+o polygons
+v 0 0 0
+v 2 0 0
+v 2 2 0
+v 1 0.5 0
+v 0 2 0
+v 0 0 1
+v 2 0 1
+v 2 2 1
+v 1 0.5 1
+v 0 2 1
+v -1.5 0.25 -2
+v 1.25 0.5 -2.5
+v 1.5 1.75 -1
+v -0.5 2.5 -0.25
+v -1.25 1.5 -1.5
+v 0.1 1.2 -1.4
+vt 0 0
+vt 1 1
+vn 0 0 1
+# a triangle, a convex quad and a concave pentagon in the plane z = 0 (OBJL's containment test is live there)
+f 1 2 3
+f 1 2 3 5
+f 1 2 3 4 5
+# the same pentagon in z = 1 (the test is inert off the origin), as v/vt/vn, v//vn and relative indices
+f 6 7 8 9 10
+f 6/1/1 7/2/1 9/1/1 10/2/1
+f -11//1 -10//1 -9//1 -8//1 -7//1
+# a quad with a reflex corner, both rotations; a hexagon off every axis
+f 1 2 4 3
+f 2 3 4 1
+f 11 12 13 14 15 16
+f 7/1 8/2 9/1 10/2 6/1
+"""
+
+
+def obj_triangulation_fixture():
+    """Round 3: the triangle list the reference's vendored OBJ reader (source/helpers/OBJ_Loader.h, through oracle/objl_harness.cpp)
+    makes of a file with faces of 3 to 6 corners, concave ones included, plus the three cubes of BASELINE config 2 written as quads."""
+    import ctypes as C
+    import tempfile
+
+    lib = C.CDLL(os.path.join(HERE, "_ref", "libmcrt_objl.so"))
+    cubes = scenes.box_stack_obj_text()
+    out = {}
+    for tag, text in (("polygons", OBJ_TEXT), ("box_stack", cubes)):
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, tag + ".obj")
+            open(path, "w").write(text)
+            tri = np.zeros((256, 3, 3), F)
+            n = lib.objl_load_triangles(path.encode(), tri.ctypes.data_as(C.c_void_p), 256)
+            assert 0 < n <= 256
+        out[tag + "_text"] = np.frombuffer(text.encode(), np.uint8)
+        out[tag + "_triangles"] = tri[:n].copy()
+    assert len(out["box_stack_triangles"]) == 36
+    save("obj_triangulation.npz", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if not po.Ref.available():
@@ -384,6 +443,9 @@ def main():
     print("F9 the per-object virtuals (Object::Intersects / GetSurfaceNormal / GetRandomPointOnSurface of every object alone)")
     for name, sc_h, fl in (("cornell", cornell, flat), ("cornell_point", point, pflat), ("cornell_sphere_light", ssc, sflat2), ("hexagon", hexa, hflat)):
         object_api_fixture(R, name, sc_h, fl, np.random.default_rng([20261203, len(name)]))
+
+    print("F10 OBJ triangulation (the reference's OBJ library itself)")
+    obj_triangulation_fixture()
 
     print("F6 images (accumulator sums)")
     cam128 = R.camera(128, 128, 90.0, (0, 0, 5), (0, 0, 0))

@@ -136,37 +136,46 @@ def test_host_scene_builders_match_reference_dump(pkg, host, scene_of, which, po
     _same_scene(got, want)
 
 
-def test_host_obj_loader_is_index_correct(pkg, host, scene_of, tmp_path):
-    """TriangleMesh::LoadMesh replacement: quads fan-triangulated by their indices (the reference's loader
-    ignores them).  The box-stack geometry written as an OBJ gives BASELINE config 2."""
-    want = scene_of("config2")
-    stack = want.triangles[48:]                      # the 36 triangles scenes.config2 appended
-    pos = np.array([0.0, -4.0, 1.5], np.float32)
-    lines = ["# box stack", "o stack"]
-    faces = []
-    for q in range(0, len(stack), 2):                # (a,b,c),(a,c,d) -> quad a b c d
-        a, b, c, d = stack["v0"][q], stack["v1"][q], stack["v2"][q], stack["v2"][q + 1]
-        base = len(lines) - 2 + 1
-        for v in (a, b, c, d):
-            v = v - pos
-            lines.append("v %.9g %.9g %.9g" % tuple(float(x) for x in v))
-        faces.append("f %d/1/1 %d/2/1 %d/3/1 %d/4/1" % (base, base + 1, base + 2, base + 3))
-    path = tmp_path / "stack.obj"
-    path.write_text("\n".join(lines + faces) + "\n")
+def _load_obj_through_host(pkg, host, text, tmp_path, name, position=(0.0, 0.0, 0.0)):
+    path = tmp_path / name
+    path.write_text(text)
     s = host.mcrt_host_scene_create(0, 1.5, 10.0, 0)
     try:
         # the example scene puts the light last; an OBJ added afterwards becomes object 11
-        n = host.mcrt_host_scene_add_obj(s, str(path).encode(), 0.0, -4.0, 1.5, 0.5)
-        assert n == 36
+        n = host.mcrt_host_scene_add_obj(s, str(path).encode(), *[float(x) for x in position], 0.5)
         got = _flatten(pkg, host, s)
     finally:
         host.mcrt_host_scene_destroy(s)
     mesh = got.objects[11]
-    assert mesh["kind"] == pkg.abi.OBJECT_MESH and mesh["triangle_count"] == 36
-    tri = got.triangles[mesh["first_triangle"]:]
-    # vertices survive the text round trip to within an ulp of the offset subtraction; topology is exact
-    assert np.allclose(tri["v0"], stack["v0"], atol=1e-6) and np.allclose(tri["v1"], stack["v1"], atol=1e-6)
-    assert np.allclose(tri["v2"], stack["v2"], atol=1e-6) and np.allclose(tri["normal"], stack["normal"], atol=1e-5)
+    assert mesh["kind"] == pkg.abi.OBJECT_MESH and mesh["triangle_count"] == n
+    return got.triangles[mesh["first_triangle"]:]
+
+
+def test_host_obj_loader_triangulates_like_the_reference_library(pkg, host, golden, tmp_path):
+    """TriangleMesh::LoadMesh replacement against the reference's own OBJ library (fixture F10: source/helpers/OBJ_Loader.h run by
+    oracle/objl_harness.cpp): triangles, quads, concave pentagons in and off the plane through the origin, a hexagon, every index
+    form - same triangles, same corner order, same sequence, vertex for vertex."""
+    g = golden("obj_triangulation.npz")
+    for tag in ("polygons", "box_stack"):
+        tri = _load_obj_through_host(pkg, host, bytes(g[tag + "_text"]).decode(), tmp_path, tag + ".obj")
+        want = g[tag + "_triangles"] + np.float32(0.0)     # LoadMesh adds the mesh position, here (0, 0, 0), to every vertex (mesh.cpp:98-100): -0 becomes +0
+        assert len(tri) == len(want)
+        got = np.stack([tri["v0"], tri["v1"], tri["v2"]], axis=1)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), tag
+    assert len(g["polygons_triangles"]) == 1 + 2 + 3 + 3 + 2 + 3 + 2 + 2 + 4 + 3
+
+
+def test_host_obj_loader_is_index_correct(pkg, host, scene_of, tmp_path):
+    """The box-stack geometry written as an OBJ (24 vertices, 18 quads by index) and offset by the mesh position gives the mesh of
+    BASELINE config 2 (the reference's loader ignores the indices)."""
+    from mcrt_amd import scenes
+
+    want = scene_of("config2")
+    stack = want.triangles[48:]                      # the 36 triangles scenes.config2 appended
+    tri = _load_obj_through_host(pkg, host, scenes.box_stack_obj_text(), tmp_path, "stack.obj", position=(0.0, -4.0, 1.5))
+    assert len(tri) == 36
+    for k in ("v0", "v1", "v2", "normal"):
+        assert np.array_equal(tri[k].view(np.uint32), stack[k].view(np.uint32)), k
     assert host.mcrt_host_scene_add_obj(host.mcrt_host_scene_create(0, 1.5, 10.0, 0), b"/nonexistent.obj", 0, 0, 0, 0.5) == -1
 
 
