@@ -179,6 +179,25 @@ int mcrt_upload_scene_device_build(mcrt_ctx* ctx, const mcrt_scene_desc* scene,
                                    const mcrt_accel_params* accel);
 int mcrt_last_build_ms(mcrt_ctx* ctx, float* out_ms);
 
+/* The cheap half of an edit: primitives that only MOVED since the upload - the same
+ * objects with the same kinds and triangle counts; `scene` is the whole edited scene,
+ * `moved_objects` the indices of the objects whose geometry changed (materials may
+ * change anywhere).  When every primitive of those objects is still referenced
+ * wherever the builder's rule wants a reference (a move inside the cells that already
+ * hold it), the tree stays: kernels rewrite the triangle data inlined in the leaf
+ * records and refit every node's tight box bottom-up (a few passes over the node
+ * array, well under a millisecond for 10^6 triangles).  Otherwise - a primitive left
+ * its cells, or the scene is not the same set of objects - the call falls back to
+ * mcrt_upload_scene_device_build with the parameters of the tree in use and sets
+ * *out_rebuilt = 1 (may be NULL).  Either way queries answer as the brute force of
+ * source/scene.cpp:62-80 on the edited scene.  The reference's counterpart is its
+ * incremental Octree::InsertIfOverlaps (source/accelerationstructures/octree.h:50-70).
+ * A primitive listed as not moved that did move is the caller's error (its old
+ * references are trusted).  After a refit that kept the tree mcrt_last_build_ms reports
+ * the refit's kernel time. */
+int mcrt_refit_scene(mcrt_ctx* ctx, const mcrt_scene_desc* scene, uint32_t moved_count,
+                     const uint32_t* moved_objects, int* out_rebuilt);
+
 /* Camera::Camera + Camera::SetView, source/core/camera.h:19-34; also sizes
  * and zeroes the PixelBuffer accumulators (source/core/pixelbuffer.cpp:7-23):
  * the accumulator in use is cleared, a caller-bound one included.  When the

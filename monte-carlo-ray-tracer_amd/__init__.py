@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(HERE, "libmcrt_hip.so")
 
 # every symbol include/mcrt.h declares
 ABI_SYMBOLS = (
-    "mcrt_create", "mcrt_destroy", "mcrt_last_error", "mcrt_set_stream", "mcrt_upload_scene", "mcrt_upload_scene_device_build", "mcrt_last_build_ms", "mcrt_set_camera", "mcrt_set_accel",
+    "mcrt_create", "mcrt_destroy", "mcrt_last_error", "mcrt_set_stream", "mcrt_upload_scene", "mcrt_upload_scene_device_build", "mcrt_refit_scene", "mcrt_last_build_ms", "mcrt_set_camera", "mcrt_set_accel",
     "mcrt_camera_rays", "mcrt_intersect", "mcrt_intersect_device", "mcrt_intersect_noalloc", "mcrt_trace_samples", "mcrt_trace_rays", "mcrt_render_unlit", "mcrt_rng_seed",
     "mcrt_clear", "mcrt_dropped_samples", "mcrt_bind_accumulator", "mcrt_accumulator", "mcrt_render", "mcrt_last_render_ms", "mcrt_resolve",
     "mcrt_read_accumulator", "mcrt_write_accumulator", "mcrt_synchronize", "mcrt_octree_info_get", "mcrt_octree_download", "mcrt_set_counting", "mcrt_counters",
@@ -159,6 +159,14 @@ class Backend:
         d = flat.desc()
         fn = self.lib.mcrt_upload_scene_device_build if device_build else self.lib.mcrt_upload_scene
         self._ck(fn(self.ctx, C.byref(d), C.byref(accel) if accel is not None else None))
+
+    def refit_scene(self, flat, moved_objects):
+        """mcrt_refit_scene: True when the tree was kept and refitted, False when the call fell back to a rebuild."""
+        d = flat.desc()
+        mv = np.ascontiguousarray(moved_objects, np.uint32)
+        rebuilt = C.c_int(0)
+        self._ck(self.lib.mcrt_refit_scene(self.ctx, C.byref(d), C.c_uint32(len(mv)), _ptr(mv, C.c_uint32), C.byref(rebuilt)))
+        return rebuilt.value == 0
 
     def last_build_ms(self):
         ms = C.c_float()

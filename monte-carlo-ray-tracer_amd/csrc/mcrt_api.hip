@@ -1741,6 +1741,56 @@ int mcrt_upload_scene(mcrt_ctx* c, const mcrt_scene_desc* scene, const mcrt_acce
 
 int mcrt_upload_scene_device_build(mcrt_ctx* c, const mcrt_scene_desc* scene, const mcrt_accel_params* accel) { return upload_scene_impl(c, scene, accel, true); }
 
+int mcrt_refit_scene(mcrt_ctx* c, const mcrt_scene_desc* scene, uint32_t moved_count, const uint32_t* moved_objects, int* out_rebuilt)
+{
+    if (out_rebuilt) *out_rebuilt = 0;
+    int rc = need_scene(c, false);
+    if (rc) return rc;
+    if (moved_count && !moved_objects) return fail(c, MCRT_ERR_INVALID, "null list of moved objects");
+    const mcrt_accel_params accel = { c->flat.max_leaf, c->flat.max_depth, c->flat.pad_rel };      // the parameters the tree in use was built with
+    auto rebuild = [&]() {
+        if (out_rebuilt) *out_rebuilt = 1;
+        return upload_scene_impl(c, scene, &accel, true);
+    };
+    FlatScene flat;
+    std::string err;
+    rc = flatten_scene(scene, &accel, flat, err, false);
+    if (rc) return fail(c, rc, err);
+    // same objects, same kinds, same triangle ranges, same light list: otherwise this is another scene
+    const SceneView& v = c->view;
+    bool same = flat.view.nobj == v.nobj && flat.view.ntri == v.ntri && flat.view.nprim == v.nprim && flat.view.nlights == v.nlights &&
+                flat.view.small_words == v.small_words && flat.view.has_pairs == v.has_pairs && flat.view.off_pair == v.off_pair - v.off_tri;
+    for (uint32_t i = 0; same && i < v.nobj; ++i) {
+        const uint32_t* a = flat.small_img.data() + flat.view.off_obj + (size_t)i * OBJ_STRIDE;
+        const uint32_t* b = c->flat.small_img.data() + v.off_obj + (size_t)i * OBJ_STRIDE;
+        same = a[OBJ_KIND] == b[OBJ_KIND] && a[OBJ_FIRST_TRI] == b[OBJ_FIRST_TRI] && a[OBJ_TRI_COUNT] == b[OBJ_TRI_COUNT] && a[OBJ_FIRST_PRIM] == b[OBJ_FIRST_PRIM];
+        // a sphere that crosses the "never intersects" radius (source/objects/sphere.h:18) enters or leaves the tree
+        if (same && a[OBJ_KIND] == (uint32_t)MCRT_OBJECT_SPHERE)
+            same = (__builtin_bit_cast(float, a[OBJ_RADIUS]) >= 1.1920928955078125e-07f) == (__builtin_bit_cast(float, b[OBJ_RADIUS]) >= 1.1920928955078125e-07f);
+    }
+    for (uint32_t k = 0; same && k < v.nlights; ++k) same = flat.small_img[flat.view.off_lights + k] == c->flat.small_img[v.off_lights + k];
+    if (!same) return rebuild();
+    std::vector<uint8_t> moved(v.nobj, 0);
+    for (uint32_t k = 0; k < moved_count; ++k) {
+        if (moved_objects[k] >= v.nobj) return fail(c, MCRT_ERR_INVALID, "moved object index outside the scene");
+        moved[moved_objects[k]] = 1;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_small, flat.small_img.data(), flat.small_img.size() * 4, hipMemcpyHostToDevice, c->stream));
+    if (!flat.big_img.empty()) HIP_TRY(c, hipMemcpyAsync(c->d_big + v.off_tri, flat.big_img.data(), flat.big_img.size() * 4, hipMemcpyHostToDevice, c->stream));
+    bld::Params P = { v.nobj, v.nprim, v.ntri, c->flat.max_leaf, c->flat.max_depth, c->flat.stay, c->flat.pad_rel };
+    uint32_t why = 0;
+    float ms = 0.0f;
+    const int r = bld::refit_on_device(c->stream, P, c->d_small, v.off_obj, scene->triangle_count ? &scene->triangles[0].v0[0] : nullptr, moved, c->d_big, v.off_node,
+                                       v.off_leaf, v.off_tri, v.nnode, c->flat.ref_count, c->flat.tree_depth, c->flat.root_cell, c->flat.pad, why, ms, err);
+    if (r == 1) return fail(c, MCRT_ERR_HIP, err);
+    if (r == 2) return rebuild();          // a moved primitive left the cells that reference it (the triangle records were overwritten: the rebuild rewrites everything)
+    c->flat.small_img = flat.small_img;
+    c->last_build_ms = ms;
+    c->tree_on_host = false;               // the host copies of the node boxes are stale: read back on demand
+    return MCRT_OK;
+}
+
 int mcrt_last_build_ms(mcrt_ctx* c, float* out_ms)
 {
     if (!c || !out_ms) return MCRT_ERR_INVALID;

@@ -541,5 +541,216 @@ inline int build_on_device(hipStream_t stream, const Params& P, const uint32_t* 
     return 0;
 }
 
+// ---------------------------------------------------------------- refit (second half)
+// A scene whose primitives only MOVED since the tree was built - same objects, same triangle counts - keeps its tree when every moved
+// primitive is still referenced wherever the builder's rule wants a reference: at every node on the way down, the node's own list holds
+// it, or every child whose padded cell the primitive (padded box, then the triangle itself: the builder's two tests) now overlaps
+// exists and passes the same check.  Extra references do no harm (a test that misses), a missing one would hide a hit - then the
+// caller rebuilds.  What is recomputed: the inlined triangle data of the leaf records and every node's tight box, bottom-up.
+// The reference's counterpart is Octree::InsertIfOverlaps (source/accelerationstructures/octree.h:50-70), its incremental entry point.
+
+// a node's cell from its record (min corner + 2^-depth): the builder's max corner to within an ulp; users add `slack`
+__device__ __forceinline__ void rf_cell(const uint32_t* w, const float* root_size, float* cmn, float* cmx)
+{
+    const float scale = __uint_as_float(w[NODE_SCALE]);
+    for (int a = 0; a < 3; ++a) { cmn[a] = __uint_as_float(w[NODE_CELL + a]); cmx[a] = cmn[a] + root_size[a] * scale; }
+}
+
+struct RefitArgs {
+    const uint32_t* big;          // records (read) ...
+    uint32_t off_node, off_leaf;
+    float root_size[3], root_min[3], root_max[3], pad;
+};
+
+// The builder's cell of the node reached from the root by `path` (3 bits per level, the root's choice in the lowest bits): the
+// float formulas of k_bld_children / Builder::make applied level by level, so the corners are the builder's own bit for bit.
+__device__ __forceinline__ void rf_cell_by_path(const float* root_min, const float* root_max, uint64_t path, uint32_t depth, float* cmn, float* cmx)
+{
+    for (int a = 0; a < 3; ++a) { cmn[a] = root_min[a]; cmx[a] = root_max[a]; }
+    for (uint32_t l = 0; l < depth; ++l) {
+        const uint32_t c = (uint32_t)(path >> (3u * l)) & 7u;
+        for (int a = 0; a < 3; ++a) {
+            const float half = 0.5f * (cmx[a] - cmn[a]), centre = cmn[a] + half;
+            if ((c >> a) & 1u) cmn[a] = centre; else cmx[a] = centre;
+        }
+    }
+}
+
+// one thread per primitive of a moved object: is it still referenced wherever the BUILDER's rule (k_bld_classify: padded-box overlap
+// with the child cell, then the triangle against the padded child cell) wants a reference?  fail[0] != 0: no
+__global__ void k_rf_check(RefitArgs A, Params P, uint32_t nprim, const uint8_t* __restrict__ moved_obj, const uint32_t* __restrict__ prim_obj, const uint8_t* __restrict__ prim_skip,
+                           const float* __restrict__ pbox, const float* __restrict__ raw_tris, const uint32_t* __restrict__ small_img, uint32_t off_obj, uint32_t* __restrict__ fail)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nprim) return;
+    const uint32_t obj = prim_obj[p];
+    if (!moved_obj[obj] || prim_skip[p]) return;
+    const float pad = A.pad;
+    float bmn[3], bmx[3];
+    for (int a = 0; a < 3; ++a) { bmn[a] = pbox[(size_t)p * 6 + a] - pad; bmx[a] = pbox[(size_t)p * 6 + 3 + a] + pad; }
+    // inside the root cell (the builder's root cell holds every padded box with a padding to spare)
+    for (int a = 0; a < 3; ++a)
+        if (!(bmn[a] >= A.root_min[a] && bmx[a] <= A.root_max[a])) { atomicOr(fail, 1u); return; }
+    const uint32_t* o = small_img + off_obj + obj * OBJ_STRIDE;
+    const bool tri = o[OBJ_KIND] != (uint32_t)MCRT_OBJECT_SPHERE;
+    const float* t = tri ? raw_tris + (size_t)(o[OBJ_FIRST_TRI] + (p - o[OBJ_FIRST_PRIM])) * 12 : nullptr;
+    constexpr int kStack = 8 * MAX_TREE_DEPTH + 8;
+    uint32_t stack[kStack];         // node index | depth << 24
+    uint64_t paths[kStack];
+    int sp = 0;
+    stack[0] = 0u; paths[0] = 0ull; sp = 1;
+    while (sp > 0) {
+        --sp;
+        const uint32_t node = stack[sp] & 0x00FFFFFFu, depth = stack[sp] >> 24;
+        const uint64_t path = paths[sp];
+        const uint32_t* w = A.big + A.off_node + (size_t)node * NODE_STRIDE;
+        bool own = false;
+        if (w[NODE_LEAF] != NO_REFS) {
+            for (uint32_t r = w[NODE_LEAF];; ++r) {
+                const uint32_t e = A.big[A.off_leaf + (size_t)r * LEAF_STRIDE + LEAF_PRIM];
+                if ((e & ~REF_LAST) == p) { own = true; break; }
+                if (e & REF_LAST) break;
+            }
+        }
+        if (own) continue;
+        const uint32_t cw = w[NODE_CHILD], mask = cw >> 24, base = cw & 0x00FFFFFFu;
+        if (!mask) { atomicOr(fail, 2u); return; }
+        float cmn[3], cmx[3], centre[3];
+        rf_cell_by_path(A.root_min, A.root_max, path, depth, cmn, cmx);
+        for (int a = 0; a < 3; ++a) centre[a] = cmn[a] + 0.5f * (cmx[a] - cmn[a]);
+        for (uint32_t c = 0; c < 8; ++c) {
+            float kmn[3], kmx[3];
+            bool over = true;
+            for (int a = 0; a < 3; ++a) {
+                const bool hi = (c >> a) & 1u;
+                kmn[a] = hi ? centre[a] : cmn[a];
+                kmx[a] = hi ? cmx[a] : centre[a];
+                if (bmx[a] < kmn[a] || kmx[a] < bmn[a]) over = false;
+            }
+            if (!over) continue;
+            if (tri) {
+                float pmn[3], pmx[3];
+                for (int a = 0; a < 3; ++a) { pmn[a] = kmn[a] - pad; pmx[a] = kmx[a] + pad; }
+                if (!tri_overlaps_box(t, pmn, pmx)) continue;
+            }
+            if (!(mask & (1u << c))) { atomicOr(fail, 4u); return; }
+            if (sp >= kStack || depth >= 255u) { atomicOr(fail, 8u); return; }
+            stack[sp] = (base + (uint32_t)__popc(mask & ((1u << c) - 1u))) | ((depth + 1u) << 24);
+            paths[sp] = path | ((uint64_t)c << (3u * depth));
+            ++sp;
+        }
+    }
+}
+
+// leaf records of moved meshes: v0 / edge1 / edge2 again from the (re-uploaded) triangle records
+__global__ void k_rf_leaves(uint32_t nrefs, uint32_t* __restrict__ big, uint32_t off_leaf, uint32_t off_tri, const uint8_t* __restrict__ moved_obj,
+                            const uint32_t* __restrict__ small_img, uint32_t off_obj)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrefs) return;
+    uint32_t* w = big + off_leaf + (size_t)r * LEAF_STRIDE;
+    const uint32_t ow = w[LEAF_OBJ];
+    if (ow & LEAF_SPHERE) return;
+    if (!moved_obj[ow]) return;
+    const uint32_t* o = small_img + off_obj + ow * OBJ_STRIDE;
+    const uint32_t prim = w[LEAF_PRIM] & ~REF_LAST;
+    const uint32_t* tr = big + off_tri + (size_t)(o[OBJ_FIRST_TRI] + (prim - o[OBJ_FIRST_PRIM])) * TRI_STRIDE;
+    for (uint32_t k = 0; k < 9; ++k) w[k] = tr[k];
+}
+
+// per node: the union of its OWN members' padded boxes clipped to the padded cell -> box[node][6] (min xyz, max xyz; empty: +max / -max)
+__global__ void k_rf_own(RefitArgs A, uint32_t nodes, const float* __restrict__ pbox, float* __restrict__ box)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nodes) return;
+    const uint32_t* w = A.big + A.off_node + (size_t)n * NODE_STRIDE;
+    float mn[3] = { 3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f }, mx[3] = { -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f };
+    if (w[NODE_LEAF] != NO_REFS) {
+        float cmn[3], cmx[3];
+        rf_cell(w, A.root_size, cmn, cmx);
+        const float grow = A.pad + A.pad * (1.0f / 64.0f);
+        for (uint32_t r = w[NODE_LEAF];; ++r) {
+            const uint32_t e = A.big[A.off_leaf + (size_t)r * LEAF_STRIDE + LEAF_PRIM], p = e & ~REF_LAST;
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = fminf(mn[a], fmaxf(pbox[(size_t)p * 6 + a] - A.pad, cmn[a] - grow));
+                mx[a] = fmaxf(mx[a], fminf(pbox[(size_t)p * 6 + 3 + a] + A.pad, cmx[a] + grow));
+            }
+            if (e & REF_LAST) break;
+        }
+    }
+    for (int a = 0; a < 3; ++a) { box[(size_t)n * 6 + a] = mn[a]; box[(size_t)n * 6 + 3 + a] = mx[a]; }
+}
+
+// one sweep of box[node] = box[node] U box[children]: after (tree depth) sweeps every box holds its whole subtree (boxes only grow, so
+// a sweep that reads a child mid-update is harmless)
+__global__ void k_rf_up(RefitArgs A, uint32_t nodes, float* __restrict__ box)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nodes) return;
+    const uint32_t cw = A.big[A.off_node + (size_t)n * NODE_STRIDE + NODE_CHILD], mask = cw >> 24, base = cw & 0x00FFFFFFu;
+    if (!mask) return;
+    float b[6];
+    for (int k = 0; k < 6; ++k) b[k] = box[(size_t)n * 6 + k];
+    const uint32_t kids = (uint32_t)__popc(mask);
+    for (uint32_t c = 0; c < kids; ++c)
+        for (int a = 0; a < 3; ++a) {
+            b[a] = fminf(b[a], box[(size_t)(base + c) * 6 + a]);
+            b[3 + a] = fmaxf(b[3 + a], box[(size_t)(base + c) * 6 + 3 + a]);
+        }
+    for (int k = 0; k < 6; ++k) box[(size_t)n * 6 + k] = b[k];
+}
+
+__global__ void k_rf_store(uint32_t nodes, const float* __restrict__ box, uint32_t* __restrict__ big, uint32_t off_node)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nodes) return;
+    if (box[(size_t)n * 6] > box[(size_t)n * 6 + 3]) return;           // nothing below (the root of an empty scene): the record keeps its box
+    uint32_t* w = big + off_node + (size_t)n * NODE_STRIDE;
+    for (int k = 0; k < 6; ++k) w[NODE_BOX + k] = __float_as_uint(box[(size_t)n * 6 + k]);
+}
+
+// Returns 0 (refitted), 2 (the tree no longer fits: `why` holds the check's verdict, nothing usable changed - rebuild) or 1 with `err` set.
+// d_big already holds the NEW triangle / pair records at off_tri; d_small the new SMALL image.
+inline int refit_on_device(hipStream_t stream, const Params& P, const uint32_t* d_small, uint32_t off_obj, const float* h_raw_tris, const std::vector<uint8_t>& moved,
+                           uint32_t* d_big, uint32_t off_node, uint32_t off_leaf, uint32_t off_tri, uint32_t nnode, uint32_t nrefs, uint32_t depth, const float root_cell[6],
+                           float pad, uint32_t& why, float& kernel_ms, std::string& err)
+{
+    struct Events {
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } events;
+    BLD_TRY(hipEventCreate(&events.a)); BLD_TRY(hipEventCreate(&events.b));
+    Buf<float> raw, pbox, box;
+    Buf<uint32_t> prim_obj, fail;
+    Buf<uint8_t> skip, moved_d;
+    Buf<int> rootbox;
+    BLD_TRY(raw.alloc((size_t)P.ntri * 12)); BLD_TRY(pbox.alloc((size_t)P.nprim * 6)); BLD_TRY(prim_obj.alloc(P.nprim)); BLD_TRY(skip.alloc(P.nprim));
+    BLD_TRY(rootbox.alloc(8)); BLD_TRY(fail.alloc(1)); BLD_TRY(moved_d.alloc(moved.size())); BLD_TRY(box.alloc((size_t)nnode * 6));
+    if (P.ntri) BLD_TRY(hipMemcpyAsync(raw.p, h_raw_tris, (size_t)P.ntri * 48, hipMemcpyHostToDevice, stream));
+    BLD_TRY(hipMemcpyAsync(moved_d.p, moved.data(), moved.size(), hipMemcpyHostToDevice, stream));
+    BLD_TRY(hipEventRecord(events.a, stream));
+    BLD_TRY(hipMemsetAsync(fail.p, 0, 4, stream));
+    const int init_box[8] = { 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0 };
+    BLD_TRY(hipMemcpyAsync(rootbox.p, init_box, sizeof init_box, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_bld_boxes, dim3(blocks_for(P.nprim)), dim3(kThreads), 0, stream, P, d_small, off_obj, raw.p, pbox.p, prim_obj.p, skip.p, rootbox.p);
+    RefitArgs A;
+    A.big = d_big; A.off_node = off_node; A.off_leaf = off_leaf; A.pad = pad;
+    for (int a = 0; a < 3; ++a) { A.root_min[a] = root_cell[a]; A.root_max[a] = root_cell[3 + a]; A.root_size[a] = root_cell[3 + a] - root_cell[a]; }
+    hipLaunchKernelGGL(k_rf_check, dim3(blocks_for(P.nprim)), dim3(kThreads), 0, stream, A, P, P.nprim, moved_d.p, prim_obj.p, skip.p, pbox.p, raw.p, d_small, off_obj, fail.p);
+    BLD_TRY(hipGetLastError());
+    BLD_TRY(hipMemcpyAsync(&why, fail.p, 4, hipMemcpyDeviceToHost, stream));
+    BLD_TRY(hipStreamSynchronize(stream));
+    if (why) return 2;
+    if (nrefs) hipLaunchKernelGGL(k_rf_leaves, dim3(blocks_for(nrefs)), dim3(kThreads), 0, stream, nrefs, d_big, off_leaf, off_tri, moved_d.p, d_small, off_obj);
+    hipLaunchKernelGGL(k_rf_own, dim3(blocks_for(nnode)), dim3(kThreads), 0, stream, A, nnode, pbox.p, box.p);
+    for (uint32_t s = 0; s <= depth; ++s) hipLaunchKernelGGL(k_rf_up, dim3(blocks_for(nnode)), dim3(kThreads), 0, stream, A, nnode, box.p);
+    hipLaunchKernelGGL(k_rf_store, dim3(blocks_for(nnode)), dim3(kThreads), 0, stream, nnode, box.p, d_big, off_node);
+    BLD_TRY(hipGetLastError());
+    BLD_TRY(hipEventRecord(events.b, stream));
+    BLD_TRY(hipStreamSynchronize(stream));
+    BLD_TRY(hipEventElapsedTime(&kernel_ms, events.a, events.b));
+    return 0;
+}
+
 } // namespace bld
 } // namespace mcrt

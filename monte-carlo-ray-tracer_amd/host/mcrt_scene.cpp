@@ -399,6 +399,24 @@ void Scene::PrepareForRayTracing()
     prepared = true;
 }
 
+bool Scene::ObjectsMoved(const std::vector<unsigned int>& indices, bool* rebuilt)
+{
+    if (!prepared) return Fail("ObjectsMoved before PrepareForRayTracing");
+    mcrt_scene_desc desc;
+    Flatten(desc);
+    std::vector<uint32_t> moved(indices.begin(), indices.end());
+    int again = 0;
+    if (mcrt_refit_scene(ctx, &desc, (uint32_t)moved.size(), moved.data(), &again) != MCRT_OK) { prepared = false; return Fail("refit_scene"); }
+    if (rebuilt) *rebuilt = again != 0;
+    mcrt_last_build_ms(ctx, &octree.lastBuildMs);
+    mcrt_octree_info info;
+    if (mcrt_octree_info_get(ctx, &info) == MCRT_OK) {
+        octree.nodeCount = info.node_count; octree.primitiveRefs = info.prim_ref_count;
+        octree.depth = info.max_depth; octree.ldsResident = info.lds_resident != 0;
+    }
+    return true;
+}
+
 bool Scene::Bind(Camera& camera)
 {
     if (boundCamera == &camera) return true;
@@ -1005,6 +1023,22 @@ void mcrt_host_trace_unlit(void* scene, uint64_t n, const float* o, const float*
         const ColorDbl c = s.TraceUnlit(Ray(vec3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), vec3(d[3 * i], d[3 * i + 1], d[3 * i + 2])));
         out[3 * i] = c.r; out[3 * i + 1] = c.g; out[3 * i + 2] = c.b;
     }
+}
+
+// Scene::ObjectsMoved (test hook): object `index` translated by (dx, dy, dz) - a sphere's centre, a mesh's vertices - then the refit
+int mcrt_host_scene_move_object(void* scene, unsigned index, float dx, float dy, float dz, int* out_rebuilt)
+{
+    Scene* s = static_cast<Scene*>(scene);
+    if (index >= s->ObjectCount()) return 1;
+    Object* ob = s->GetObject(index);
+    const vec3 delta(dx, dy, dz);
+    ob->position = ob->position + delta;
+    if (TriangleMesh* mesh = dynamic_cast<TriangleMesh*>(ob))
+        for (Triangle& t : mesh->triangles) t = Triangle(t.vertex0 + delta, t.vertex1 + delta, t.vertex2 + delta);
+    bool rebuilt = false;
+    if (!s->ObjectsMoved({ index }, &rebuilt)) return 2;
+    if (out_rebuilt) *out_rebuilt = rebuilt ? 1 : 0;
+    return 0;
 }
 
 int mcrt_host_scene_flatten(void* scene, mcrt_scene_desc* out) { return static_cast<Scene*>(scene)->Flatten(*out) ? 0 : 1; }

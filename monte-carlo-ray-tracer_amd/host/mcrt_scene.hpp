@@ -247,6 +247,11 @@ public:
 
     // Light cache + UpdateAABB (source/scene.cpp:41-55), then flatten and upload (replaces octree.Fill, :58).
     void PrepareForRayTracing();
+    // After PrepareForRayTracing: the listed objects (indices into `objects`) MOVED - same kinds, same triangle counts.  The tree is
+    // kept and refitted on the device when every moved primitive is still inside the cells that reference it, rebuilt on the device
+    // otherwise (mcrt_refit_scene; the reference's incremental entry point is Octree::InsertIfOverlaps, octree.h:50-70).
+    // *rebuilt (may be null) tells which; octree.lastBuildMs holds the device time of whichever ran.
+    bool ObjectsMoved(const std::vector<unsigned int>& indices, bool* rebuilt = nullptr);
     // The flat description PrepareForRayTracing uploads (no device needed).
     bool Flatten(mcrt_scene_desc& out);
 

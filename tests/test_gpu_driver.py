@@ -387,6 +387,142 @@ def test_device_rebuild_after_an_edit(backend, pkg, oracle, scene_of, golden):
         backend.set_accel(pkg.ACCEL_AUTO)
 
 
+def _with_mesh_vertices(pkg, flat, obj_index, fn):
+    """A copy of `flat` whose mesh `obj_index` has its vertices mapped through fn(v0, v1, v2) -> (v0, v1, v2); normals and the
+    mesh's gate box follow (TriangleMesh::UpdateAABB starts from `position`, source/objects/mesh.cpp:49-68)."""
+    edited = pkg.FlatScene(flat.objects.copy(), flat.triangles.copy(), flat.background)
+    o = edited.objects[obj_index]
+    sl = slice(int(o["first_triangle"]), int(o["first_triangle"]) + int(o["triangle_count"]))
+    tri = edited.triangles[sl]
+    v0, v1, v2 = fn(tri["v0"].astype(np.float32), tri["v1"].astype(np.float32), tri["v2"].astype(np.float32))
+    tri["v0"], tri["v1"], tri["v2"] = v0.astype(np.float32), v1.astype(np.float32), v2.astype(np.float32)
+    n = np.cross(tri["v1"] - tri["v0"], tri["v2"] - tri["v0"]).astype(np.float32)
+    tri["normal"] = (n / np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-30)).astype(np.float32)
+    edited.triangles[sl] = tri
+    verts = np.concatenate([tri["v0"], tri["v1"], tri["v2"], edited.objects["position"][obj_index][None, :]])
+    edited.objects["aabb_min"][obj_index] = verts.min(axis=0)
+    edited.objects["aabb_max"][obj_index] = verts.max(axis=0)
+    return edited
+
+
+def _hits_equal_brute_force(backend, pkg, oracle, flat, o, d, modes=None):
+    sc = oracle.scene(flat)
+    wobj, welem, wt = oracle.intersect(sc, o, d)
+    for mode in modes or (pkg.ACCEL_OCTREE, pkg.ACCEL_AUTO):
+        backend.set_accel(mode)
+        obj, elem, t = backend.intersect(o, d)
+        assert np.array_equal(obj, wobj) and np.array_equal(elem, welem) and np.array_equal(t.view(np.uint32), wt.view(np.uint32)), mode
+    backend.set_accel(pkg.ACCEL_AUTO)
+
+
+@pytest.mark.parametrize("device_build", [True, False])
+def test_refit_after_primitives_moved(backend, pkg, oracle, scene_of, golden, device_build):
+    """mcrt_refit_scene (the incremental half of octree.h:50-70): triangles that shrink inside their old extent keep the tree - the
+    call must NOT rebuild - and a mesh carried across the room does not - the call must rebuild; either way every query answers as
+    the brute force over the edited scene, a render equals the render through a tree built from scratch, and a second refit on top
+    of the first works from the refitted state."""
+    flat = scene_of("config4_2k")
+    g = golden("hits_config4_2k.npz")
+    o, d = g["origins"][:30000], g["dirs"][:30000]
+    cam = oracle.camera(64, 48, 90.0, POS, TGT)
+    big = int(np.argmax(flat.objects["triangle_count"]))
+    backend.upload_scene(flat, device_build=device_build)
+    info0 = backend.octree_info()
+
+    def shrink(f):
+        def fn(v0, v1, v2):
+            c = (v0 + v1 + v2) / np.float32(3.0)
+            return tuple((c + (v - c) * np.float32(f)).astype(np.float32) for v in (v0, v1, v2))
+        return fn
+
+    cur = flat
+    for f in (0.8, 0.5):
+        cur = _with_mesh_vertices(pkg, cur, big, shrink(f))
+        assert backend.refit_scene(cur, [big]) is True, "a triangle inside its old extent overlaps no new cell"
+        info = backend.octree_info()
+        assert (info.node_count, info.prim_ref_count) == (info0.node_count, info0.prim_ref_count)
+        _hits_equal_brute_force(backend, pkg, oracle, cur, o, d)
+        backend.set_accel(pkg.ACCEL_OCTREE)
+        backend.set_camera(cam)
+        backend.clear(); backend.render(0, 6, 100, SEED)
+        a = backend.read_accumulator()
+        # the CPU replay of the refitted tree (downloaded) equals the brute force too
+        box, words, refs = backend.octree_download()
+        sc = oracle.scene(cur)
+        wobj, welem, wt = oracle.intersect(sc, o[:5000], d[:5000])
+        robj, relem, rt = oracle.intersect_octree(sc, info, box, words, refs, o[:5000], d[:5000])
+        assert np.array_equal(robj, wobj) and np.array_equal(relem, welem) and np.array_equal(rt, wt)
+        # ... and the render through a tree built from scratch for the edited scene
+        b2 = pkg.Backend(0)
+        try:
+            b2.upload_scene(cur)
+            b2.set_accel(pkg.ACCEL_OCTREE)
+            b2.set_camera(cam)
+            b2.clear(); b2.render(0, 6, 100, SEED)
+            assert np.array_equal(a, b2.read_accumulator())
+        finally:
+            b2.close()
+        backend.set_accel(pkg.ACCEL_AUTO)
+    # a box moved a little (materials of another object changed on the way): kept or rebuilt, the answers are the edited scene's
+    boxes = [i for i in range(len(flat.objects)) if 0 < int(flat.objects["triangle_count"][i]) <= 12 and i != big]
+    moved = _with_mesh_vertices(pkg, cur, boxes[-1], lambda a, b, c: (a + np.float32(1e-5), b + np.float32(1e-5), c + np.float32(1e-5)))
+    moved.objects["material"]["albedo"][boxes[0]] = np.float32(0.5)
+    backend.refit_scene(moved, [boxes[-1]])
+    _hits_equal_brute_force(backend, pkg, oracle, moved, o, d)
+    # carried across the room: the primitives leave their cells, the call falls back to the device build
+    far = _with_mesh_vertices(pkg, moved, big, lambda a, b, c: tuple(v + np.array([1.5, -0.7, 0.9], np.float32) for v in (a, b, c)))
+    assert backend.refit_scene(far, [big]) is False
+    assert backend.last_build_ms() > 0.0
+    _hits_equal_brute_force(backend, pkg, oracle, far, o, d)
+    # another set of objects is another scene: rebuilt
+    assert backend.refit_scene(scene_of("config3"), []) is False
+    g3 = golden("hits_config3.npz")
+    _hits_equal_brute_force(backend, pkg, oracle, scene_of("config3"), g3["origins"][:20000], g3["dirs"][:20000])
+    # a sphere nudged inside its cells and one carried away (config 3's spheres)
+    c3 = scene_of("config3")
+    spheres = [i for i in range(len(c3.objects)) if int(c3.objects["kind"][i]) == 0]   # MCRT_OBJECT_SPHERE
+    nudged = pkg.FlatScene(c3.objects.copy(), c3.triangles.copy(), c3.background)
+    nudged.objects["radius"][spheres[0]] *= np.float32(0.9)
+    kept = backend.refit_scene(nudged, [spheres[0]])
+    assert kept is True, "a sphere that shrinks in place stays in its cells"
+    _hits_equal_brute_force(backend, pkg, oracle, nudged, g3["origins"][:20000], g3["dirs"][:20000], (pkg.ACCEL_OCTREE, pkg.ACCEL_AUTO, pkg.ACCEL_SCAN))
+    away = pkg.FlatScene(nudged.objects.copy(), nudged.triangles.copy(), nudged.background)
+    away.objects["position"][spheres[1]] += np.array([0.8, 0.3, -0.5], np.float32)
+    backend.refit_scene(away, [spheres[1]])
+    _hits_equal_brute_force(backend, pkg, oracle, away, g3["origins"][:20000], g3["dirs"][:20000], (pkg.ACCEL_OCTREE, pkg.ACCEL_AUTO, pkg.ACCEL_SCAN))
+    backend.upload_scene(scene_of("cornell"))
+
+
+def test_refit_of_the_million_triangle_scene(backend, pkg, oracle, scene_of):
+    """The refit at BASELINE config 4's size: 10^6 triangles shrunk in place - the tree stays, the refit takes a fraction of the
+    45 ms rebuild, hits equal the oracle's brute force over the edited triangles."""
+    import time
+
+    from mcrt_amd import scenes
+
+    flat = scenes.config4(scene_of("cornell"), n=1_000_000, seed=42)
+    big = int(np.argmax(flat.objects["triangle_count"]))
+    backend.upload_scene(flat, device_build=True)
+    build_ms = backend.last_build_ms()
+
+    def fn(v0, v1, v2):
+        c = (v0 + v1 + v2) / np.float32(3.0)
+        return tuple((c + (v - c) * np.float32(0.7)).astype(np.float32) for v in (v0, v1, v2))
+
+    edited = _with_mesh_vertices(pkg, flat, big, fn)
+    t0 = time.perf_counter()
+    kept = backend.refit_scene(edited, [big])
+    wall = time.perf_counter() - t0
+    print(f"refit of {int(flat.objects['triangle_count'][big])} triangles: kept={kept}, {backend.last_build_ms():.2f} ms of kernels, {wall * 1e3:.0f} ms wall with upload (device build: {build_ms:.1f} ms)")
+    assert kept is True
+    rng = np.random.default_rng(10)
+    o = rng.uniform(-4.4, 4.4, (300, 3)).astype(np.float32)
+    d = rng.normal(size=(300, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    _hits_equal_brute_force(backend, pkg, oracle, edited, o, d, (pkg.ACCEL_OCTREE,))
+    backend.upload_scene(scene_of("cornell"))
+
+
 def test_device_build_of_the_million_triangle_scene(backend, pkg, oracle, scene_of):
     """BASELINE config 4's geometry indexed on the device: the host builder's node and reference counts, hits equal the oracle's
     brute force over all 1,000,012 triangles, per-sample radiance equal to the oracle's."""
