@@ -125,7 +125,7 @@ enum { MCRT_ACCEL_OCTREE = 0, MCRT_ACCEL_BRUTE = 1, MCRT_ACCEL_SCAN = 2, MCRT_AC
 #define MCRT_SCAN_PAIR_LIMIT 65536   /* scenes with more triangles carry no scan records: SCAN is refused */
 
 typedef struct mcrt_accel_params {
-    uint32_t max_leaf_prims;   /* Octree::maxCount analogue (octree.h:31); 0 = default */
+    uint32_t max_leaf_prims;   /* Octree::maxCount analogue (octree.h:31); 0 = default (4; 8 for scenes beyond 1024 primitives) */
     uint32_t max_depth;        /* 0 = default                               */
     float pad_rel;             /* node box padding, fraction of root extent; 0 = default */
 } mcrt_accel_params;

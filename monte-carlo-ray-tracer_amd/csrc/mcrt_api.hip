@@ -143,14 +143,25 @@ struct RenderCounters { uint32_t samples, trace_calls, splits; };
 
 template <class PB> struct WalkStackFor {
     typedef ScratchStack type;
+    static constexpr bool kDeal = false;
     static __device__ __forceinline__ void bind(type&, uint32_t*) {}
 };
 template <> struct WalkStackFor<GlbPtr> {
     typedef LdsStack type;
+    static constexpr bool kDeal = true;       // leaf records dealt over the wavefront (OctreeWalk::run_dealt)
     static __device__ __forceinline__ void bind(type& st, uint32_t* lds) { st.col = (__attribute__((address_space(3))) uint32_t*)lds + threadIdx.x; }
 };
-// LDS words the kernels that trace paths need after the SMALL image (octree walk over an HBM-resident image)
-constexpr uint32_t kWalkLdsWords = LDS_STACK_ENTRIES * 2 * LDS_STACK_BLOCK;
+// LDS words the kernels that trace paths need after the SMALL image (octree walk over an HBM-resident image): the stack columns, then the
+// deal's per-thread hit keys (u64), hit objects and owner markers
+constexpr uint32_t kWalkStackWords = LDS_STACK_ENTRIES * 2 * LDS_STACK_BLOCK;
+constexpr uint32_t kWalkLdsWords = kWalkStackWords + 3 * LDS_STACK_BLOCK;
+template <class W> __device__ __forceinline__ typename W::Deal walk_deal_area(uint32_t* walk_lds)
+{
+    typename W::Deal L;
+    L.key = (__attribute__((address_space(3))) unsigned long long*)(walk_lds + kWalkStackWords);
+    L.slot = (LdsRw)(walk_lds + kWalkStackWords + 2 * LDS_STACK_BLOCK);
+    return L;
+}
 static_assert(LDS_STACK_BLOCK == kBlock, "LdsStack columns are one per thread of the block");
 
 // Scheduling knobs of trace_lane (wave-uniform runtime values, so that they can be swept without rebuilding):
@@ -455,6 +466,9 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
     WalkStackFor<PB>::bind(walk_stack, walk_lds);
     bool walking = false;
     if (kWalk) walk.idle();
+    constexpr bool kDeal = kWalk && WalkStackFor<PB>::kDeal;
+    const typename OctreeWalk<PS, PB, kCount>::Deal deal = walk_deal_area<OctreeWalk<PS, PB, kCount>>(walk_lds);
+    if constexpr (kDeal) { deal.slot[threadIdx.x] = 0u; wave_sync(); }      // no marker yet (tag 0 is never a deal's)
 
     // The loop is wave-uniform: a lane that has nothing left stays in it as a helper (the cooperative queries need all 64 lanes).
     for (;;) {
@@ -492,10 +506,16 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
             }
             if constexpr (kWalk) {
                 // a lane without a ray has an empty stack: it sits in the walk loop as a finished lane
-                if (live && !walking) { walk.begin(sm, big, v, walk_stack, ln.ro, ln.rd, cn); walking = true; }
-                walk.run(sm, big, v, walk_stack, ln.ro, ln.rd, cn, policy.refill);
+                if constexpr (kDeal) {
+                    if (live && !walking) { walk.begin_dealt(sm, big, v, walk_stack, deal, ln.ro, ln.rd, cn); walking = true; }
+                    walk.run_dealt(sm, big, v, walk_stack, deal, ln.ro, ln.rd, cn, policy.refill);
+                } else {
+                    if (live && !walking) { walk.begin(sm, big, v, walk_stack, ln.ro, ln.rd, cn); walking = true; }
+                    walk.run(sm, big, v, walk_stack, ln.ro, ln.rd, cn, policy.refill);
+                }
                 if (!live || !walk.done()) continue;          // no ray, or still in mid-traversal: nothing to shade yet
                 walking = false;
+                if constexpr (kDeal) walk.collect_dealt(sm, v, deal);
                 hit = walk.best;
             } else {
                 hit = cast<kAccel, PS, PB, kCount>(sm, big, v, ln.ro, ln.rd, cn, live);
@@ -537,6 +557,7 @@ struct RenderArgs {
     unsigned long long* dropped;    // non-finite samples dropped since the last mcrt_clear (mcrt_dropped_samples)
     unsigned long long* counters;   // 8 x u64 (kCount builds)
     uint32_t* pend;
+    void* park;                 // [chunks][launched lanes] x 16 bytes: the estimator state of the lanes that walk an HBM-resident octree (trace_lane_parked)
     uint32_t s_begin, s_count, max_depth;
     uint32_t tiles_x, tiles;    // pixel tiles of (64 >> wave_slices_log2) pixels
     uint32_t wave_slices_log2;  // slices of one pixel that share a wavefront
@@ -618,7 +639,7 @@ struct RenderWork {
 };
 
 template <bool kBigLds, int kAccel, bool kCount, bool kMulti>
-__global__ __launch_bounds__(kBlock, 4) void k_render(const RenderArgs a)
+__global__ __launch_bounds__(kBlock, (kAccel == MCRT_ACCEL_OCTREE && !kBigLds) ? MCRT_WALK_BLOCKS : 4) void k_render(const RenderArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     typedef SceneMem<kBigLds, kAccel> Mem;
@@ -638,7 +659,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_render(const RenderArgs a)
     if ((threadIdx.x & 63u) < 32u) prof_slots()[threadIdx.x & 63u] = 0ull;
     const unsigned long long pt_kernel = PROF_NOW();
 #endif
-    trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount, kMulti>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, false, cn, rc, work, a.policy, walk_lds);
+    if constexpr (kAccel == MCRT_ACCEL_OCTREE && !kBigLds)
+        trace_lane_parked<typename Mem::PS, typename Mem::PB, kCount, kMulti>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, cn, rc, work, a.policy, walk_lds, (U4*)a.park,
+                                                                                gridDim.x * blockDim.x);
+    else
+        trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount, kMulti>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, false, cn, rc, work, a.policy, walk_lds);
 #ifdef MCRT_SECTION_PROFILE
     PROF_ADD(PF_WAVES, 1); PROF_ADD(PF_TOTAL_T, PROF_NOW() - pt_kernel);
     if ((threadIdx.x & 63u) < (uint32_t)PF_COUNT) atomicAdd(&g_prof[threadIdx.x & 63u], prof_slots()[threadIdx.x & 63u]);
@@ -740,6 +765,75 @@ __device__ __forceinline__ void wf_load(LaneState<kMulti>& s, uint32_t& slice, c
         s.g_l.s0 = (uint64_t)e.x | ((uint64_t)e.y << 32); s.g_l.s1 = (uint64_t)e.z | ((uint64_t)e.w << 32);
     } else {
         s.hn = mk(0, 0, 0); s.hd = mk(0, 0, 0); s.g_l.s0 = 0; s.g_l.s1 = 0;
+    }
+}
+
+// The render loop for an octree walked from HBM (the 1M-triangle mesh).  trace_lane keeps the whole estimator state (LaneState, ~64
+// registers) live across the walk; at the 128 registers of four wavefronts per SIMD the compiler then spills the walk's own hot
+// variables (the stack pointer, the list counter) to scratch, and every reload waits for ALL outstanding loads - the node and leaf
+// records included, which serialises the very round trips the walk tries to overlap.  Here the state is PARKED in HBM between two
+// shadings (wf_store / wf_load, the chunk-major layout of the wavefront pipeline, slot = launched lane): a lane carries its ray and
+// its state word through the walk and nothing else, and loads the rest only when its query is answered - post, pre, store.  Same
+// LaneState code, same numbers.  512 bytes of coalesced traffic per query against the ~3 KB of records a walk fetches.
+template <class PS, class PB, bool kCount, bool kMulti>
+__device__ __forceinline__ void trace_lane_parked(PS sm, PB big, const SceneView& v, const CameraDev& cam, uint64_t seed, uint32_t max_depth, const PendStack& pend,
+                                                  Counters& cn, RenderCounters& rc, RenderWork& work, const LanePolicy policy, uint32_t* walk_lds, U4* park, uint32_t slots)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t state = ST_FETCH;
+    V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+    {
+        LaneState<kMulti> ln;
+        ln.init();
+        wf_store(ln, 0u, park, slots, slot);
+    }
+    ExplicitStart exs;
+    const ExplicitStart* ex = nullptr;
+    const uint32_t kMinTrace = policy.min_trace, kFetchMin = policy.fetch_min;
+    typedef OctreeWalk<PS, PB, kCount> Walk;
+    Walk walk;
+    typename WalkStackFor<PB>::type walk_stack;
+    WalkStackFor<PB>::bind(walk_stack, walk_lds);
+    bool walking = false;
+    walk.idle();
+    const typename Walk::Deal deal = walk_deal_area<Walk>(walk_lds);
+    deal.slot[threadIdx.x] = 0u;          // no marker yet (tag 0 is never a deal's)
+    wave_sync();
+    for (;;) {
+        const uint64_t busy = __ballot(state != ST_DONE);
+        if (busy == 0ull) break;
+        bool fetch_ok = true;
+        if (kFetchMin > 1u) {
+            const uint64_t want = __ballot(state == ST_FETCH);
+            fetch_ok = (uint32_t)__popcll(want) >= kFetchMin || want == busy;
+        }
+        if ((state == ST_FETCH && fetch_ok) || state == ST_NEW) {
+            LaneState<kMulti> ln;
+            wf_load(ln, work.slice, park, slots, slot);
+            ln.pre(fetch_ok, work, cam, seed, max_depth, exs, ex, rc, kCount);
+            wf_store(ln, work.slice, park, slots, slot);
+            state = ln.state; ro = ln.ro; rd = ln.rd;
+        }
+        bool live = state != ST_FETCH && state != ST_DONE;
+        if (kMinTrace > 0u && live) {
+            const bool is_s = state == ST_SHADOW;
+            const uint32_t n_s = (uint32_t)__popcll(__ballot(is_s)), n_t = (uint32_t)__popcll(__ballot(!is_s));
+            live = is_s || n_t >= kMinTrace || n_s == 0u;
+        }
+        if (live && !walking) { walk.begin_dealt(sm, big, v, walk_stack, deal, ro, rd, cn); walking = true; }
+        walk.run_dealt(sm, big, v, walk_stack, deal, ro, rd, cn, policy.refill);
+        if (!live || !walk.done()) continue;          // no ray, or still in mid-traversal: nothing to shade yet
+        walking = false;
+        walk.collect_dealt(sm, v, deal);
+        {
+            LaneState<kMulti> ln;
+            wf_load(ln, work.slice, park, slots, slot);
+            const D3 background = ldd3(sm, v.off_bg);
+            ln.post(walk.best, sm, big, v, background, pend, false, work, ex, rc, kCount);
+            if (ln.state == ST_NEW || (ln.state == ST_FETCH && kFetchMin <= 1u)) ln.pre(true, work, cam, seed, max_depth, exs, ex, rc, kCount);
+            wf_store(ln, work.slice, park, slots, slot);
+            state = ln.state; ro = ln.ro; rd = ln.rd;
+        }
     }
 }
 
@@ -1181,6 +1275,8 @@ struct mcrt_ctx {
     unsigned long long* d_dropped = nullptr;    // dropped (non-finite) samples since the last clear
     uint32_t grid_mult = 4;                     // persistent workgroups per CU (MCRT_GRID_MULT, tuning knob)
     uint32_t* d_pend = nullptr;
+    void* d_park = nullptr;                     // parked estimator state of the render kernel's lanes (octree walked from HBM)
+    size_t park_bytes = 0;
     size_t pend_words = 0;
     uint32_t grid_blocks = 0;
     uint32_t lanes_override = 0;                // mcrt_set_lanes_per_pixel (0: automatic)
@@ -1275,6 +1371,18 @@ int ensure_pend(mcrt_ctx* c, uint32_t max_depth)
         if (c->d_pend) { HIP_TRY(c, hipFree(c->d_pend)); c->d_pend = nullptr; c->pend_words = 0; }
         HIP_TRY(c, hipMalloc(&c->d_pend, words * sizeof(uint32_t)));
         c->pend_words = words;
+    }
+    return MCRT_OK;
+}
+
+// The parked estimator state (trace_lane_parked): 16-byte chunks, chunk-major, one column per launched lane.
+int ensure_park(mcrt_ctx* c)
+{
+    const size_t bytes = (size_t)grid_for(c) * kBlock * kWfChunksMulti * 16u;
+    if (bytes > c->park_bytes) {
+        if (c->d_park) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(c->d_park)); c->d_park = nullptr; c->park_bytes = 0; }
+        HIP_TRY(c, hipMalloc(&c->d_park, bytes));
+        c->park_bytes = bytes;
     }
     return MCRT_OK;
 }
@@ -1486,7 +1594,7 @@ LanePolicy lane_policy(const mcrt_ctx* c)
     p.fetch_min = c->fetch_min_override >= 1 ? (uint32_t)c->fetch_min_override : (walk_hbm ? 1u : 64u);
     // measured (profiles/r01_refill_sweep.txt): refilling pays when the image is walked from HBM/L2 (long, exponentially distributed
     // walks); with an LDS-resident image the extra shading passes cost more than they save
-    const uint32_t refill = c->refill_override >= 0 ? (uint32_t)c->refill_override : (c->big_in_lds ? 0u : 40u);
+    const uint32_t refill = c->refill_override >= 0 ? (uint32_t)c->refill_override : (c->big_in_lds ? 0u : 24u);
     p.refill = refill;
     return p;
 }
@@ -1631,6 +1739,7 @@ int mcrt_destroy(mcrt_ctx* c)
     if (c->d_resolve_img) (void)hipFree(c->d_resolve_img);
     if (c->d_resolve_mean) (void)hipFree(c->d_resolve_mean);
     if (c->d_pend) (void)hipFree(c->d_pend);
+    if (c->d_park) (void)hipFree(c->d_park);
     if (c->d_wf_state) (void)hipFree(c->d_wf_state);
     if (c->d_wf_hits) (void)hipFree(c->d_wf_hits);
     if (c->d_wf_queue) (void)hipFree(c->d_wf_queue);
@@ -2163,10 +2272,13 @@ int mcrt_render(mcrt_ctx* c, uint32_t sample_begin, uint32_t sample_count, uint3
     const bool wavefront = use_wavefront(c);
     rc = wavefront ? ensure_wavefront(c, max_depth) : ensure_pend(c, max_depth);
     if (rc) return rc;
+    const bool parked = !wavefront && c->accel == MCRT_ACCEL_OCTREE && !c->big_in_lds;
+    if (parked && (rc = ensure_park(c)) != MCRT_OK) return rc;
     HIP_TRY(c, hipMemsetAsync(c->d_tile, 0, 2 * sizeof(uint32_t), c->stream));
     if (c->counting) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
     RenderArgs a;
     a.view = view_for(c); a.cam = c->cam; a.accum = c->d_accum; a.tile_counter = c->d_tile; a.dropped = c->d_dropped; a.counters = c->d_counters; a.pend = c->d_pend;
+    a.park = parked ? c->d_park : nullptr;
     a.s_begin = sample_begin; a.s_count = sample_count; a.max_depth = max_depth;
     a.policy = lane_policy(c);
     a.slices = c->lanes_override ? std::min<uint32_t>(c->lanes_override, sample_count) : mcrt_lanes_per_pixel(c->cam.width, c->cam.height, sample_count);

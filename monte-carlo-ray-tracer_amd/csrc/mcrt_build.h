@@ -329,7 +329,7 @@ __global__ void k_bld_emit_nodes(uint32_t nodes, Nodes N, uint32_t* __restrict__
     w[NODE_CHILD] = N.child_word[f];
     w[NODE_LEAF] = N.own_count[f] ? N.own_begin[f] : NO_REFS;
     for (int k = 0; k < 3; ++k) w[NODE_CELL + k] = __float_as_uint(N.cell[(size_t)f * 6 + k]);
-    w[NODE_SCALE] = __float_as_uint(ldexpf(1.0f, -(int)N.depth[f]));
+    w[NODE_SCALE] = __float_as_uint(ldexpf(1.0f, -(int)N.depth[f])) | (N.own_count[f] & NODE_COUNT_MASK);
 }
 
 __global__ void k_bld_emit_leaves(uint32_t nrefs, const uint32_t* __restrict__ refs, const uint32_t* __restrict__ prim_obj, const uint32_t* __restrict__ small_img,
@@ -552,7 +552,7 @@ inline int build_on_device(hipStream_t stream, const Params& P, const uint32_t* 
 // a node's cell from its record (min corner + 2^-depth): the builder's max corner to within an ulp; users add `slack`
 __device__ __forceinline__ void rf_cell(const uint32_t* w, const float* root_size, float* cmn, float* cmx)
 {
-    const float scale = __uint_as_float(w[NODE_SCALE]);
+    const float scale = __uint_as_float(w[NODE_SCALE] & NODE_SCALE_MASK);
     for (int a = 0; a < 3; ++a) { cmn[a] = __uint_as_float(w[NODE_CELL + a]); cmx[a] = cmn[a] + root_size[a] * scale; }
 }
 

@@ -511,7 +511,13 @@ struct ScratchStack {
 // block: bank = thread id, conflict-free whatever the lanes' stack depths), the rest in scratch memory.  Scratch
 // is dword-interleaved per wavefront, so 64 lanes pushing at 64 different depths touch 64 different cache lines:
 // measured on the 1M-triangle scene, a scratch-only stack was most of the kernel's HBM traffic.
-constexpr int LDS_STACK_ENTRIES = 18;
+#ifndef MCRT_LDS_STACK
+#define MCRT_LDS_STACK 16
+#endif
+#ifndef MCRT_WALK_BLOCKS
+#define MCRT_WALK_BLOCKS 4
+#endif
+constexpr int LDS_STACK_ENTRIES = MCRT_LDS_STACK;     // 16 entries + the deal's arrays = the 36 KB per block that 18 entries took: four blocks per CU
 constexpr int LDS_STACK_BLOCK = 256;
 template <int kEntries> struct LdsStackT {
     __attribute__((address_space(3))) uint32_t* col;      // this thread's column
@@ -534,6 +540,29 @@ template <int kEntries> struct LdsStackT {
     MCRT_DEV void put_fast(int i, float t, uint32_t w) { col[(i * 2 + 0) * LDS_STACK_BLOCK] = __float_as_uint(t); col[(i * 2 + 1) * LDS_STACK_BLOCK] = w; }
 };
 typedef LdsStackT<LDS_STACK_ENTRIES> LdsStack;
+// The same stack through a handle that is passed BY VALUE (the column pointer and the addresses of the deep part): a loop that works
+// through it keeps the handle in registers, where a reference to the LdsStackT object - which lives in scratch memory because of its
+// dynamically indexed arrays - made every access re-read the column pointer from scratch.
+template <int kEntries> struct LdsStackRef {
+    __attribute__((address_space(3))) uint32_t* col;
+    float* t_;
+    uint32_t* w_;
+    MCRT_DEV explicit LdsStackRef(LdsStackT<kEntries>& s) : col(s.col), t_(s.t_), w_(s.w_) {}
+    MCRT_DEV void put(int i, float t, uint32_t w) const
+    {
+        if (i < kEntries) { col[(i * 2 + 0) * LDS_STACK_BLOCK] = __float_as_uint(t); col[(i * 2 + 1) * LDS_STACK_BLOCK] = w; }
+        else { t_[i - kEntries] = t; w_[i - kEntries] = w; }
+    }
+    MCRT_DEV void both(int i, float& t, uint32_t& w) const
+    {
+        if (i < kEntries) { t = __uint_as_float(col[(i * 2 + 0) * LDS_STACK_BLOCK]); w = col[(i * 2 + 1) * LDS_STACK_BLOCK]; }
+        else { t = t_[i - kEntries]; w = w_[i - kEntries]; }
+    }
+    MCRT_DEV bool room(int i, int n) const { return i + n <= kEntries; }
+    MCRT_DEV void put_fast(int i, float t, uint32_t w) const { col[(i * 2 + 0) * LDS_STACK_BLOCK] = __float_as_uint(t); col[(i * 2 + 1) * LDS_STACK_BLOCK] = w; }
+};
+MCRT_DEV LdsStackRef<LDS_STACK_ENTRIES> stack_handle(LdsStack& s) { return LdsStackRef<LDS_STACK_ENTRIES>(s); }
+MCRT_DEV ScratchStack& stack_handle(ScratchStack& s) { return s; }
 
 // Reciprocal of a direction component for the slab and plane tests of the walk.  A zero (or tiny) component would give
 // +-inf, and (face - origin) * inf is NaN when the origin lies exactly on the face - min/max drop the NaN and the node
@@ -548,14 +577,40 @@ MCRT_DEV float slab_rcp(float d)
     return fabsf(r) <= kWalkRcpMax ? r : copysignf(kWalkRcpMax, d);
 }
 
+// Inclusive scans over the 64 lanes of the wavefront with DPP row shifts and row broadcasts (no LDS traffic).  All lanes active.
+#define MCRT_DPP(X, CTRL, ROWS) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(X), (CTRL), (ROWS), 0xf, true))
+MCRT_DEV uint32_t wave_scan_add(uint32_t x)
+{
+    x += MCRT_DPP(x, 0x111, 0xf);     // row_shr:1 (lanes shifted in from outside the row of 16 read 0)
+    x += MCRT_DPP(x, 0x112, 0xf);     // row_shr:2
+    x += MCRT_DPP(x, 0x114, 0xf);     // row_shr:4
+    x += MCRT_DPP(x, 0x118, 0xf);     // row_shr:8
+    x += MCRT_DPP(x, 0x142, 0xa);     // row_bcast:15 into rows 1 and 3
+    x += MCRT_DPP(x, 0x143, 0xc);     // row_bcast:31 into rows 2 and 3
+    return x;
+}
+MCRT_DEV uint32_t wave_scan_max(uint32_t x)
+{
+    x = max(x, MCRT_DPP(x, 0x111, 0xf));
+    x = max(x, MCRT_DPP(x, 0x112, 0xf));
+    x = max(x, MCRT_DPP(x, 0x114, 0xf));
+    x = max(x, MCRT_DPP(x, 0x118, 0xf));
+    x = max(x, MCRT_DPP(x, 0x142, 0xa));
+    x = max(x, MCRT_DPP(x, 0x143, 0xc));
+    return x;
+}
+#undef MCRT_DPP
+
 template <class PS, class PB, bool kCount> struct OctreeWalk {
     Hit best;
     uint64_t gate_known, gate_pass;
     int sp;               // entries on the stack
     uint32_t pleaf;       // next record of the leaf list the lane is working off, NO_REFS: none
+    uint32_t pcnt;        // dealt walk only: records of that list still to be tested
+    uint32_t epoch;       // dealt walk only: tag of the owner markers of the current deal (wave-uniform; lives as long as the LDS it tags)
 
     MCRT_DEV bool done() const { return sp == 0 && pleaf == NO_REFS; }      // the ray is finished, `best` is its answer
-    MCRT_DEV void idle() { sp = 0; pleaf = NO_REFS; gate_known = gate_pass = 0; best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax; }
+    MCRT_DEV void idle() { sp = 0; pleaf = NO_REFS; pcnt = 0; epoch = 0; gate_known = gate_pass = 0; best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax; }
 
     // Scenes with at most this many objects have every mesh gate evaluated when the ray starts - by all the lanes that start together -
     // instead of on first contact: evaluated lazily, about one lane of the wavefront meets a new mesh in every step, and the whole
@@ -570,7 +625,7 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
         // and shadow ray, any camera within ~26 scene sizes - never take this branch.)
         if (!(fabsf(o.x) <= v.far_limit && fabsf(o.y) <= v.far_limit && fabsf(o.z) <= v.far_limit)) {
             best = cast_brute<PS, PB, kCount>(sm, big, v, o, d, cn);
-            sp = 0; pleaf = NO_REFS;
+            sp = 0; pleaf = NO_REFS; pcnt = 0;
             return;
         }
         best.prim = MISS; best.obj = MISS; best.elem = 0; best.t = kFltMax;
@@ -584,8 +639,68 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
             }
             gate_known = ~0ull;
         }
-        pleaf = NO_REFS;
+        pleaf = NO_REFS; pcnt = 0;
         st.put(0, 0.0f, 0u); sp = 1;          // the root
+    }
+
+    // The octants of a node that the ray passes inside [tb0, tb1], pushed far to near (cw: the node's child word, rc: its cell words).
+    template <class St> static MCRT_DEV void push_octants(St& st, int& sp, float best_t, uint32_t cw, const U4& rc, float tb0, float tb1, V3 o, V3 inv, V3 padt, V3 dts, uint32_t flip)
+    {
+        const uint32_t mask = cw >> 24;
+        {
+            const uint32_t base = cw & 0x00FFFFFFu;
+            const float scale = __uint_as_float(rc.w & NODE_SCALE_MASK);
+            // Which octants, in which order?  A straight line meets each of the cell's three mid planes once, so inside [tb0, tb1] it
+            // passes at most four octants: the one it is in at tb0 and one more per mid plane crossed (Revelles' parametric walk).
+            // In ray order (bit a of r set = beyond the mid plane of axis a): r starts with the planes already behind at tb0; every
+            // plane crossed before tb1 flips its bit, nearest crossing first.  Everything is decided with the padding on the
+            // generous side: a plane counts as behind only when it is more than the padding behind, as crossed when it comes within
+            // the padding of [tb0, tb1], and the octant beyond it is entered the padding early.  A hit point always lies in the padded
+            // cell of the octant that is current at its distance (per axis it is on the same side of the mid plane or within the
+            // padding of it), and the builder references a primitive from every child whose padded cell it overlaps - so the
+            // primitive is met there, and the entry distance is not behind it (ties included).  "The padding" of these decisions
+            // (padt) is HALF the builder's: the distances below carry a rounding error of a few ulps of max(|origin|, |cell|), and
+            // with the builder's full padding a slow ray that runs 2e-7 OUTSIDE the padded neighbour cell was routed through that
+            // neighbour - which does not reference the primitive - for the rest of its way (round 2's hole; tests: pad_margin_rays).
+            // With half of it the walk's "within reach of the child" is always inside the builder's.  The octant test this replaces
+            // worked out all eight padded boxes (max3 / min3 / compare each) and pushed in a loop: ~225 instructions, now ~90.
+            const float cmn[3] = { __uint_as_float(rc.x), __uint_as_float(rc.y), __uint_as_float(rc.z) };
+            const float oo[3] = { o.x, o.y, o.z }, ii[3] = { inv.x, inv.y, inv.z }, pp[3] = { padt.x, padt.y, padt.z }, dd[3] = { dts.x, dts.y, dts.z };
+            uint32_t r0 = 0;
+            float c[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                // the mid plane from the cell's corner: the cell is the root cell scaled by 2^-depth, half of dts * scale away
+                const float tm = __fmaf_rn(dd[k] * scale, 0.5f, (cmn[k] - oo[k]) * ii[k]);
+                const float enter = tm - pp[k];                       // where the half beyond the plane begins for this ray
+                const bool behind = enter < tb0 - 2.0f * pp[k] ? true : false;      // tm < tb0 - pad
+                r0 |= behind ? (1u << k) : 0u;
+                c[k] = (!behind && enter <= tb1) ? enter : __builtin_inff();
+            }
+            // the three crossings in order (a three-element sorting network; the axis bit travels with its distance)
+            float k0 = c[0], k1 = c[1], k2 = c[2];
+            uint32_t b0 = 1u, b1 = 2u, b2 = 4u;
+            if (k1 < k0) { const float t = k0; k0 = k1; k1 = t; const uint32_t u = b0; b0 = b1; b1 = u; }
+            if (k2 < k1) { const float t = k1; k1 = k2; k2 = t; const uint32_t u = b1; b1 = b2; b2 = u; }
+            if (k1 < k0) { const float t = k0; k0 = k1; k1 = t; const uint32_t u = b0; b0 = b1; b1 = u; }
+            const uint32_t r1 = r0 ^ b0, r2 = r1 ^ b1, r3 = r2 ^ b2;
+            // far to near; an octant whose entry lies behind the best hit so far (or that is not entered at all: +inf) is left out
+            const bool fast = st.room(sp, 4);
+#define MCRT_PUSH_OCTANT(R, T)                                                                   \
+            {                                                                                    \
+                const uint32_t oct = (R) ^ flip;                                                 \
+                if ((mask >> oct) & 1u) {                                                        \
+                    const uint32_t child = base + __popc(mask & ((1u << oct) - 1u));             \
+                    if (fast) st.put_fast(sp, (T), child); else st.put(sp, (T), child);          \
+                    ++sp;                                                                        \
+                }                                                                                \
+            }
+            if (k2 <= best_t) MCRT_PUSH_OCTANT(r3, fmaxf(tb0, k2))
+            if (k1 <= best_t) MCRT_PUSH_OCTANT(r2, fmaxf(tb0, k1))
+            if (k0 <= best_t) MCRT_PUSH_OCTANT(r1, fmaxf(tb0, k0))
+            MCRT_PUSH_OCTANT(r0, tb0)
+#undef MCRT_PUSH_OCTANT
+        }
     }
 
     // One step of the walk, the same two pieces of code for every lane of the wavefront:
@@ -640,61 +755,7 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
                 asm volatile("" ::: "memory");
                 loaded = true;
             }
-            const uint32_t cw = rb.z, mask = cw >> 24;
-            if (mask) {
-                const uint32_t base = cw & 0x00FFFFFFu;
-                const float scale = __uint_as_float(rc.w);
-                // Which octants, in which order?  A straight line meets each of the cell's three mid planes once, so inside [tb0, tb1] it
-                // passes at most four octants: the one it is in at tb0 and one more per mid plane crossed (Revelles' parametric walk).
-                // In ray order (bit a of r set = beyond the mid plane of axis a): r starts with the planes already behind at tb0; every
-                // plane crossed before tb1 flips its bit, nearest crossing first.  Everything is decided with the padding on the
-                // generous side: a plane counts as behind only when it is more than the padding behind, as crossed when it comes within
-                // the padding of [tb0, tb1], and the octant beyond it is entered the padding early.  A hit point always lies in the padded
-                // cell of the octant that is current at its distance (per axis it is on the same side of the mid plane or within the
-                // padding of it), and the builder references a primitive from every child whose padded cell it overlaps - so the
-                // primitive is met there, and the entry distance is not behind it (ties included).  "The padding" of these decisions
-                // (padt) is HALF the builder's: the distances below carry a rounding error of a few ulps of max(|origin|, |cell|), and
-                // with the builder's full padding a slow ray that runs 2e-7 OUTSIDE the padded neighbour cell was routed through that
-                // neighbour - which does not reference the primitive - for the rest of its way (round 2's hole; tests: pad_margin_rays).
-                // With half of it the walk's "within reach of the child" is always inside the builder's.  The octant test this replaces
-                // worked out all eight padded boxes (max3 / min3 / compare each) and pushed in a loop: ~225 instructions, now ~90.
-                const float cmn[3] = { __uint_as_float(rc.x), __uint_as_float(rc.y), __uint_as_float(rc.z) };
-                const float oo[3] = { o.x, o.y, o.z }, ii[3] = { inv.x, inv.y, inv.z }, pp[3] = { padt.x, padt.y, padt.z }, dd[3] = { dts.x, dts.y, dts.z };
-                uint32_t r0 = 0;
-                float c[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    // the mid plane from the cell's corner: the cell is the root cell scaled by 2^-depth, half of dts * scale away
-                    const float tm = __fmaf_rn(dd[k] * scale, 0.5f, (cmn[k] - oo[k]) * ii[k]);
-                    const float enter = tm - pp[k];                       // where the half beyond the plane begins for this ray
-                    const bool behind = enter < tb0 - 2.0f * pp[k] ? true : false;      // tm < tb0 - pad
-                    r0 |= behind ? (1u << k) : 0u;
-                    c[k] = (!behind && enter <= tb1) ? enter : __builtin_inff();
-                }
-                // the three crossings in order (a three-element sorting network; the axis bit travels with its distance)
-                float k0 = c[0], k1 = c[1], k2 = c[2];
-                uint32_t b0 = 1u, b1 = 2u, b2 = 4u;
-                if (k1 < k0) { const float t = k0; k0 = k1; k1 = t; const uint32_t u = b0; b0 = b1; b1 = u; }
-                if (k2 < k1) { const float t = k1; k1 = k2; k2 = t; const uint32_t u = b1; b1 = b2; b2 = u; }
-                if (k1 < k0) { const float t = k0; k0 = k1; k1 = t; const uint32_t u = b0; b0 = b1; b1 = u; }
-                const uint32_t r1 = r0 ^ b0, r2 = r1 ^ b1, r3 = r2 ^ b2;
-                // far to near; an octant whose entry lies behind the best hit so far (or that is not entered at all: +inf) is left out
-                const bool fast = st.room(sp, 4);
-#define MCRT_PUSH_OCTANT(R, T)                                                                   \
-                {                                                                                    \
-                    const uint32_t oct = (R) ^ flip;                                                 \
-                    if ((mask >> oct) & 1u) {                                                        \
-                        const uint32_t child = base + __popc(mask & ((1u << oct) - 1u));             \
-                        if (fast) st.put_fast(sp, (T), child); else st.put(sp, (T), child);          \
-                        ++sp;                                                                        \
-                    }                                                                                \
-                }
-                if (k2 <= best.t) MCRT_PUSH_OCTANT(r3, fmaxf(tb0, k2))
-                if (k1 <= best.t) MCRT_PUSH_OCTANT(r2, fmaxf(tb0, k1))
-                if (k0 <= best.t) MCRT_PUSH_OCTANT(r1, fmaxf(tb0, k0))
-                MCRT_PUSH_OCTANT(r0, tb0)
-#undef MCRT_PUSH_OCTANT
-            }
+            if (rb.z >> 24) push_octants(st, sp, best.t, rb.z, rc, tb0, tb1, o, inv, padt, dts, flip);
         }
 
         if (pleaf != NO_REFS) {
@@ -768,6 +829,217 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
             if (walking == 0 || walking < keep) break;
             if (!done()) visit(sm, nodes, leaves, v, st, o, d, inv, padt, dts, flip, cn);
         }
+    }
+
+    // ---------------------------------------------------------------- the walk with DEALT leaf records
+    // The step above leaves the leaf half of every step to the lanes that hold a list: about a third of the wavefront, and a list of
+    // three records keeps its lane out of the node steps for three rounds.  Here the records that the lanes of a wavefront have
+    // pending - (ray, record) pairs - are laid end to end and dealt to ALL 64 lanes, one pair each: lane j finds the lane that owns
+    // pair j (a prefix sum over the list lengths, which ride in the node records), fetches that lane's ray through ds_bpermute and
+    // the record from HBM, tests it, and merges a hit into the owner's slot with one 64-bit LDS atomic min on (t, primitive id) -
+    // nearest first, then the lower id: `nearer`, i.e. the reference's tie-break (source/scene.cpp:73, source/objects/mesh.cpp:22).
+    // A list is consumed in the step in which its node was visited (unless the wavefront has more than 64 records pending), so every
+    // walking lane takes part in every node step, and the leaf tests run at the width of the wavefront.  The candidate set is the
+    // same or larger (a lane culls with the best distance as of the previous step), the winner is the minimum of the same keys.
+    struct Deal {
+        __attribute__((address_space(3))) unsigned long long* key;   // [block] per thread: (ordered t bits << 32) | primitive id of the ray's best hit
+        LdsRw slot;                                                  // [block] 64 per wavefront: owner markers of the deal
+    };
+    // float bits -> unsigned integers in the same order (a sphere can report t = -0.0, source/objects/sphere.h:44-49; every other hit is positive)
+    static MCRT_DEV uint32_t t_ord(float t) { const uint32_t b = __float_as_uint(t); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+    static MCRT_DEV float ord_t(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+    // the object that owns primitive `prim`: the last one whose first primitive id is not beyond it (ids are assigned in object order)
+    static MCRT_DEV uint32_t obj_of_prim(PS sm, const SceneView& v, uint32_t prim)
+    {
+        uint32_t lo = 0, hi = v.nobj - 1u;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1u) >> 1;
+            if (sm[v.off_obj + mid * OBJ_STRIDE + OBJ_FIRST_PRIM] <= prim) lo = mid; else hi = mid - 1u;
+        }
+        return lo;
+    }
+
+    template <class St> MCRT_DEV void begin_dealt(PS sm, PB big, const SceneView& v, St& st, const Deal& L, V3 o, V3 d, Counters& cn)
+    {
+        begin(sm, big, v, st, o, d, cn);
+        // the answer lives in LDS from here on (a far origin has it already: the loop over all objects ran in begin)
+        L.key[threadIdx.x] = ((unsigned long long)t_ord(best.t) << 32) | (unsigned long long)best.prim;
+    }
+    // the finished ray's answer back into `best`
+    MCRT_DEV void collect_dealt(PS sm, const SceneView& v, const Deal& L)
+    {
+        const unsigned long long k = L.key[threadIdx.x];
+        best.prim = (uint32_t)k;
+        if (best.prim == MISS) { best.obj = MISS; best.elem = 0; best.t = kFltMax; }
+        else {
+            best.obj = obj_of_prim(sm, v, best.prim);
+            best.t = ord_t((uint32_t)(k >> 32));
+            best.elem = best.prim - sm[v.off_obj + best.obj * OBJ_STRIDE + OBJ_FIRST_PRIM];
+        }
+    }
+
+    // The loop is software-pipelined: the record of the node a lane visits NEXT is requested before the dealt records of this step are
+    // tested (records first, node second: loads return in order and are consumed in that order), so each of the two HBM round trips
+    // of a step runs under the arithmetic of the other half.  A node requested but not yet looked at when run_dealt hands control
+    // back goes back on the stack (its entry is still there: a pop only moves the stack pointer).
+    template <class StObj> MCRT_DEV void run_dealt(PS sm, PB big, const SceneView& v, StObj& st_obj, const Deal& L, V3 o, V3 d, Counters& cn, uint32_t refill)
+    {
+        // The loop works on LOCAL copies of the walk's variables and on a by-value handle of the stack: the OctreeWalk and stack objects
+        // live in scratch memory (the stack's deep part is indexed dynamically), and a loop that went through them re-read the stack
+        // pointer, the list counter and the column pointer from scratch in every step - each reload waiting for ALL loads in flight,
+        // the node and leaf records included.
+        auto st = stack_handle(st_obj);
+        int sp = this->sp;
+        uint32_t pleaf = this->pleaf, pcnt = this->pcnt, epoch = this->epoch;
+        float best_t = this->best.t;
+        const uint32_t gate_lo = (uint32_t)gate_pass;
+        V3 inv, padt, dts;
+        uint32_t flip;
+        ray_setup(v, d, inv, padt, dts, flip);
+        const PB nodes = big + v.off_node;
+        const PB leaves = big + v.off_leaf;
+        const uint32_t lane = threadIdx.x & 63u, wbase = threadIdx.x & ~63u;
+        const bool eager = v.nobj <= kEagerGates;            // every gate of the ray is known (begin): one dword travels with the ray
+        const uint32_t entered = (uint32_t)__popcll(__ballot(sp != 0 || pleaf != NO_REFS));
+        const uint32_t keep = (entered * refill + 63u) / 64u;
+        bool have = false;                                   // ra, rb, rc hold the record of the node this lane visits next
+        U4 ra, rb, rc;
+        ra.x = ra.y = ra.z = ra.w = 0u; rb = ra; rc = ra;
+        // pop the next entry that was not entered behind the best hit so far and request its record
+#define MCRT_REQUEST_NODE()                                                                       \
+        if (pleaf == NO_REFS && sp > 0) {                                                         \
+            float t_in;                                                                           \
+            uint32_t w_in;                                                                        \
+            bool found = false;                                                                   \
+            do {                                                                                  \
+                --sp;                                                                             \
+                st.both(sp, t_in, w_in);                                                          \
+                found = !(t_in > best_t);                                                         \
+            } while (!found && sp > 0);                                                           \
+            if (found) {                                                                          \
+                const uint32_t rec = w_in * NODE_STRIDE;                                          \
+                ra = ld4(nodes, rec); rb = ld4(nodes, rec + 4); rc = ld4(nodes, rec + 8);         \
+                asm volatile("" ::: "memory");                                                    \
+                have = true;                                                                      \
+            }                                                                                     \
+        }
+        MCRT_REQUEST_NODE()
+        for (;;) {
+            const uint32_t walking = (uint32_t)__popcll(__ballot(have || sp != 0 || pleaf != NO_REFS));
+            if (walking == 0 || walking < keep) break;
+
+            // ---- node step, first half: the tight box of the node whose record has arrived
+            bool descend = false;
+            uint32_t cw = 0;
+            U4 cell = rc;
+            float tb0 = 0.0f, tb1 = 0.0f;
+            const bool any_node = __ballot(have) != 0ull;
+            if (have) {
+                have = false;
+                if (kCount) cn.nodes++;
+                tb0 = 0.0f; tb1 = best_t;
+                float p = (__uint_as_float(ra.x) - o.x) * inv.x, q = (__uint_as_float(ra.w) - o.x) * inv.x;
+                tb0 = fmaxf(tb0, fminf(p, q)); tb1 = fminf(tb1, fmaxf(p, q));
+                p = (__uint_as_float(ra.y) - o.y) * inv.y; q = (__uint_as_float(rb.x) - o.y) * inv.y;
+                tb0 = fmaxf(tb0, fminf(p, q)); tb1 = fminf(tb1, fmaxf(p, q));
+                p = (__uint_as_float(ra.z) - o.z) * inv.z; q = (__uint_as_float(rb.y) - o.z) * inv.z;
+                tb0 = fmaxf(tb0, fminf(p, q)); tb1 = fminf(tb1, fmaxf(p, q));
+                if (tb0 <= tb1) {
+                    pleaf = rb.w;
+                    pcnt = rc.w & NODE_COUNT_MASK;
+                    cw = rb.z;
+                    descend = (cw >> 24) != 0u;
+                }
+            }
+
+            // ---- the deal: pair j of the wavefront's pending records goes to lane j
+            const uint32_t cnt = pleaf != NO_REFS ? pcnt : 0u;
+            const uint32_t incl = wave_scan_add(cnt), excl = incl - cnt;
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+#ifndef MCRT_DEAL_MIN
+#define MCRT_DEAL_MIN 1
+#endif
+            // wave-uniform: the records are dealt when there are enough of them to fill most of the wavefront, or when no lane has a node to look at
+            const bool dealing = total >= (uint32_t)MCRT_DEAL_MIN || (total != 0u && !any_node);
+            bool mine = false;
+            uint32_t own = 0;
+            V3 po = o, pd = d;
+            uint32_t pgate = 0;
+            U4 a, b, c;
+            a.x = a.y = a.z = a.w = 0u; b = a; c = a;
+            if (dealing) {
+                // the markers of this deal carry a fresh tag: what earlier deals left in the slots reads as "none" (no zeroing pass)
+                epoch += 64u;
+                if (epoch == 0u) { L.slot[threadIdx.x] = 0u; wave_sync(); epoch = 64u; }     // the tag wrapped (2^26 deals): start over
+                if (cnt != 0u && excl < 64u) L.slot[wbase + excl] = epoch | lane;
+                wave_sync();
+                const uint32_t m = L.slot[threadIdx.x];
+                // owners ascend with the pairs: the marker at a list's first pair fills forward (pair 0 always carries one)
+                own = wave_scan_max((m & ~63u) == epoch ? (m & 63u) : 0u);
+                mine = lane < total;
+                const int src = (int)(own << 2);
+                const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(pleaf - excl)) + lane;     // the owner's list, (lane - excl[owner]) records in
+                po = mk(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(o.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(o.y))),
+                        __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(o.z))));
+                pd = mk(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d.y))),
+                        __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d.z))));
+                if (eager) pgate = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)gate_lo);
+                if (mine) {
+                    const uint32_t w = r * LEAF_STRIDE;
+                    a = ld4(leaves, w); b = ld4(leaves, w + 4); c = ld4(leaves, w + 8);
+                    asm volatile("" ::: "memory");             // the records travel while the octants are worked out
+                }
+                // the owners move on: what is dealt now is as good as tested
+                if (cnt != 0u) {
+                    const uint32_t room = excl < 64u ? 64u - excl : 0u;
+                    const uint32_t used = cnt < room ? cnt : room;
+                    pleaf += used; pcnt -= used;
+                    if (pcnt == 0u) pleaf = NO_REFS;
+                }
+            }
+
+            // ---- node step, second half: the octants the ray passes, far to near; then the next node is requested
+            if (descend) push_octants(st, sp, best_t, cw, cell, tb0, tb1, o, inv, padt, dts, flip);
+            MCRT_REQUEST_NODE()
+
+            // ---- the dealt records
+            if (dealing) {
+                if (mine) {
+                    bool h = false;
+                    float t = 0.0f;
+                    const uint32_t prim = c.y & ~REF_LAST;
+                    const uint32_t obj = c.z & ~LEAF_SPHERE;
+                    const uint32_t orec = v.off_obj + obj * OBJ_STRIDE;
+                    if (c.z & LEAF_SPHERE) {
+                        if (kCount) cn.spheres++;
+                        h = sphere_hit(sm, orec, po, pd, t);
+                    } else {
+                        bool pass;
+                        if (eager) pass = ((pgate >> obj) & 1u) != 0u;
+                        else {
+                            // the gate (source/objects/mesh.cpp:11-16) is a pure function of ray and mesh: evaluated on the contact
+                            if (kCount) cn.gates++;
+                            pass = gate_hit(sm, orec, po, pd);
+                        }
+                        if (pass) {
+                            if (kCount) cn.tris++;
+                            TriRec tr;
+                            tr.v0 = mk(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+                            tr.e1 = mk(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
+                            tr.e2 = mk(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x));
+                            h = tri_hit_flat(tr, po, pd, t);
+                        }
+                    }
+                    h = h && t < kFltMax;                          // a fresh best is beaten by t < FLT_MAX only (`nearer`)
+                    if (h) atomicMin((unsigned long long*)(L.key + (wbase + own)), ((unsigned long long)t_ord(t) << 32) | (unsigned long long)prim);
+                }
+                wave_sync();
+                best_t = ord_t((uint32_t)(L.key[threadIdx.x] >> 32));     // what the next pops and slabs cull with
+            }
+        }
+#undef MCRT_REQUEST_NODE
+        if (have) ++sp;          // requested, not looked at: the entry is still on the stack
+        this->sp = sp; this->pleaf = pleaf; this->pcnt = pcnt; this->epoch = epoch; this->best.t = best_t;
     }
 };
 

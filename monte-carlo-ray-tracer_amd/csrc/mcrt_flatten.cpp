@@ -302,9 +302,12 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
         if (o.material.emission[0] > 0.0 || o.material.emission[1] > 0.0 || o.material.emission[2] > 0.0) lights.push_back(i);
     }
     const uint32_t nprim = uint32_t(prim_obj.size());
+    if (prim_obj.size() > MAX_PRIMITIVES) { err = "more than 8388607 primitives (the length of a node's list is a 23-bit field of its record)"; return MCRT_ERR_LIMIT; }
 
     out.tree_built = build_tree;
-    out.max_leaf = (accel && accel->max_leaf_prims) ? accel->max_leaf_prims : 4u;
+    // default leaf size: 4 for scenes that live in LDS; 8 for the big ones, whose leaf records are dealt over the wavefront (a record costs
+    // less than a node step there: 1M triangles 73.0 -> 69.9 ms per pass, image 369 -> 271 MB; profiles/r03_octree_params.txt)
+    out.max_leaf = (accel && accel->max_leaf_prims) ? accel->max_leaf_prims : (nprim > 1024u ? 8u : 4u);
     out.max_depth = (accel && accel->max_depth) ? std::min(accel->max_depth, MAX_TREE_DEPTH) : 10u;
     out.stay = nprim > 1024u ? 4.0f : 1.0f;
     out.pad_rel = (accel && accel->pad_rel > 0.0f) ? accel->pad_rel : 1.0e-4f;
@@ -357,7 +360,7 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
 
     // ---- build -------------------------------------------------------------------------
     Builder B{ pbox, ptri, is_tri, pad, nprim > 1024u ? 4.0f : 1.0f };
-    B.max_leaf = (accel && accel->max_leaf_prims) ? accel->max_leaf_prims : 4u;
+    B.max_leaf = out.max_leaf;
     B.max_depth = (accel && accel->max_depth) ? std::min(accel->max_depth, MAX_TREE_DEPTH) : 10u;
     B.pool.reserve(1024);
     B.make(root, members, 0);
@@ -479,6 +482,11 @@ int flatten_scene(const mcrt_scene_desc* sc, const mcrt_accel_params* accel, Fla
         w[NODE_CHILD] = out.node_words[size_t(f) * 2];
         w[NODE_LEAF] = out.node_words[size_t(f) * 2 + 1];
         for (uint32_t k = 0; k < 4; ++k) w[NODE_CELL + k] = fbits(node_cell[size_t(f) * 4 + k]);
+        if (w[NODE_LEAF] != NO_REFS) {          // the length of the node's own list rides in the mantissa of the scale word
+            uint32_t n = 1;
+            for (size_t r = w[NODE_LEAF]; !(out.refs[r] & REF_LAST); ++r) ++n;
+            w[NODE_SCALE] |= n & NODE_COUNT_MASK;
+        }
     }
     for (uint32_t t = 0; t < sc->triangle_count; ++t) {
         const mcrt_triangle& tr = sc->triangles[t];

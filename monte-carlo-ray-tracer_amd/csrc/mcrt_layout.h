@@ -66,9 +66,12 @@ enum : uint32_t {
                          // only non-empty octants are stored), bits 24..31: octant mask
     NODE_LEAF = 7,       // index of this node's first leaf record, NO_REFS if none
     NODE_CELL = 8,       // min corner of the node's cell, 3 floats (the builder's own values)
-    NODE_SCALE = 11,     // 2^-depth as a float
+    NODE_SCALE = 11,     // 2^-depth as a float (sign and exponent bits, the mantissa of a power of two is zero) with the LENGTH of
+                         // the node's own list in the 23 mantissa bits: a lane that begins a list knows how many records follow
     NODE_STRIDE = 12
 };
+constexpr uint32_t NODE_SCALE_MASK = 0xFF800000u, NODE_COUNT_MASK = 0x007FFFFFu;
+constexpr uint32_t MAX_PRIMITIVES = NODE_COUNT_MASK;      // a list holds a primitive once at most
 // ---- leaf record (BIG image), LEAF_STRIDE words each, 16-byte aligned.  One per (node, primitive)
 // reference, a node's records contiguous: the triangle's v0/edge1/edge2 are INLINED, so walking a
 // node's list is one sequential stream of 48-byte records (no ref -> object -> triangle pointer
