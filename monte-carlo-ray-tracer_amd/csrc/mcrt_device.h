@@ -556,7 +556,12 @@ template <int kEntries> struct LdsStackRef {
     MCRT_DEV void both(int i, float& t, uint32_t& w) const
     {
         if (i < kEntries) { t = __uint_as_float(col[(i * 2 + 0) * LDS_STACK_BLOCK]); w = col[(i * 2 + 1) * LDS_STACK_BLOCK]; }
-        else { t = t_[i - kEntries]; w = w_[i - kEntries]; }
+        else {
+            t = t_[i - kEntries]; w = w_[i - kEntries];
+            // the deep part is scratch memory, i.e. VMEM: its loads are waited for HERE, inside the rare branch.  Left pending, every
+            // later use of the popped entry carried a vmcnt(0) - which also waits for the leaf records requested just before
+            asm volatile("" : "+v"(t), "+v"(w));
+        }
     }
     MCRT_DEV bool room(int i, int n) const { return i + n <= kEntries; }
     MCRT_DEV void put_fast(int i, float t, uint32_t w) const { col[(i * 2 + 0) * LDS_STACK_BLOCK] = __float_as_uint(t); col[(i * 2 + 1) * LDS_STACK_BLOCK] = w; }
@@ -907,21 +912,23 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
         ra.x = ra.y = ra.z = ra.w = 0u; rb = ra; rc = ra;
         // pop the next entry that was not entered behind the best hit so far and request its record
 #define MCRT_REQUEST_NODE()                                                                       \
-        if (pleaf == NO_REFS && sp > 0) {                                                         \
-            float t_in;                                                                           \
-            uint32_t w_in;                                                                        \
-            bool found = false;                                                                   \
-            do {                                                                                  \
-                --sp;                                                                             \
-                st.both(sp, t_in, w_in);                                                          \
-                found = !(t_in > best_t);                                                         \
-            } while (!found && sp > 0);                                                           \
-            if (found) {                                                                          \
-                const uint32_t rec = w_in * NODE_STRIDE;                                          \
-                ra = ld4(nodes, rec); rb = ld4(nodes, rec + 4); rc = ld4(nodes, rec + 8);         \
-                asm volatile("" ::: "memory");                                                    \
-                have = true;                                                                      \
+        {                                                                                         \
+            uint32_t w_in = 0u;                                                                   \
+            if (pleaf == NO_REFS && sp > 0) {                                                     \
+                float t_in;                                                                       \
+                bool found = false;                                                               \
+                do {                                                                              \
+                    --sp;                                                                         \
+                    st.both(sp, t_in, w_in);                                                      \
+                    found = !(t_in > best_t);                                                     \
+                } while (!found && sp > 0);                                                       \
+                have = found;                                                                     \
             }                                                                                     \
+            /* every lane loads (a lane without a node: the root's record, a cache hit): three loads that are issued on every path can be */ \
+            /* counted, and the wait for the leaf records becomes vmcnt(3) instead of vmcnt(0) - which would wait for these loads too */ \
+            const uint32_t rec = (have ? w_in : 0u) * NODE_STRIDE;                                \
+            ra = ld4(nodes, rec); rb = ld4(nodes, rec + 4); rc = ld4(nodes, rec + 8);             \
+            asm volatile("" ::: "memory");                                                        \
         }
         MCRT_REQUEST_NODE()
         for (;;) {
@@ -934,6 +941,9 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
             U4 cell = rc;
             float tb0 = 0.0f, tb1 = 0.0f;
             const bool any_node = __ballot(have) != 0ull;
+            // the requested record is waited for HERE, on every path: left pending where no lane looks at a node, it made every later write to
+            // one of its registers - the pop loop, the next request - wait for all loads in flight, the leaf records included
+            asm volatile("" ::"v"(ra.x), "v"(rb.x), "v"(rc.x));
             if (have) {
                 have = false;
                 if (kCount) cn.nodes++;
@@ -984,8 +994,9 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
                 pd = mk(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d.y))),
                         __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d.z))));
                 if (eager) pgate = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)gate_lo);
-                if (mine) {
-                    const uint32_t w = r * LEAF_STRIDE;
+                {
+                    // (lanes without a pair load record 0: loads issued on every path can be counted by the compiler's wait insertion)
+                    const uint32_t w = (mine ? r : 0u) * LEAF_STRIDE;
                     a = ld4(leaves, w); b = ld4(leaves, w + 4); c = ld4(leaves, w + 8);
                     asm volatile("" ::: "memory");             // the records travel while the octants are worked out
                 }
@@ -1005,6 +1016,9 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
             // ---- the dealt records
             if (dealing) {
                 if (mine) {
+                    // every word of the three loads stays claimed up to here: the record's spare word (c.w) had been handed out as a
+                    // temporary right after the loads were issued, and writing it meant waiting for them - before the octants
+                    asm volatile("" ::"v"(a.x), "v"(b.x), "v"(c.w));
                     bool h = false;
                     float t = 0.0f;
                     const uint32_t prim = c.y & ~REF_LAST;
