@@ -799,7 +799,15 @@ __device__ __forceinline__ void trace_lane_parked(PS sm, PB big, const SceneView
     const typename Walk::Deal deal = walk_deal_area<Walk>(walk_lds);
     deal.slot[threadIdx.x] = 0u;          // no marker yet (tag 0 is never a deal's)
     wave_sync();
+#ifdef MCRT_SECTION_PROFILE
+    unsigned long long pt_shade = 0ull;
+#endif
     for (;;) {
+#ifdef MCRT_SECTION_PROFILE
+        const unsigned long long pt_top = PROF_NOW();
+        if (pt_shade) PROF_ADD(PF_POST_T, pt_top - pt_shade);
+        PROF_ADD(PF_ITER, 1);
+#endif
         const uint64_t busy = __ballot(state != ST_DONE);
         if (busy == 0ull) break;
         bool fetch_ok = true;
@@ -820,8 +828,19 @@ __device__ __forceinline__ void trace_lane_parked(PS sm, PB big, const SceneView
             const uint32_t n_s = (uint32_t)__popcll(__ballot(is_s)), n_t = (uint32_t)__popcll(__ballot(!is_s));
             live = is_s || n_t >= kMinTrace || n_s == 0u;
         }
+#ifdef MCRT_SECTION_PROFILE
+        const unsigned long long pt_walk = PROF_NOW();
+        PROF_ADD(PF_PRE_T, pt_walk - pt_top);
+        PROF_ADD(PF_PRE_LANES, __popcll(__ballot(live && !walking)));
+#endif
         if (live && !walking) { walk.begin_dealt(sm, big, v, walk_stack, deal, ro, rd, cn); walking = true; }
         walk.run_dealt(sm, big, v, walk_stack, deal, ro, rd, cn, policy.refill);
+#ifdef MCRT_SECTION_PROFILE
+        pt_shade = PROF_NOW();
+        PROF_ADD(PF_CAST_T, pt_shade - pt_walk);
+        PROF_ADD(PF_CAST_LANES, __popcll(__ballot(live)));
+        PROF_ADD(PF_POST_TRACE_LANES, __popcll(__ballot(live && walk.done())));
+#endif
         if (!live || !walk.done()) continue;          // no ray, or still in mid-traversal: nothing to shade yet
         walking = false;
         walk.collect_dealt(sm, v, deal);
@@ -1594,7 +1613,7 @@ LanePolicy lane_policy(const mcrt_ctx* c)
     p.fetch_min = c->fetch_min_override >= 1 ? (uint32_t)c->fetch_min_override : (walk_hbm ? 1u : 64u);
     // measured (profiles/r01_refill_sweep.txt): refilling pays when the image is walked from HBM/L2 (long, exponentially distributed
     // walks); with an LDS-resident image the extra shading passes cost more than they save
-    const uint32_t refill = c->refill_override >= 0 ? (uint32_t)c->refill_override : (c->big_in_lds ? 0u : 24u);
+    const uint32_t refill = c->refill_override >= 0 ? (uint32_t)c->refill_override : (c->big_in_lds ? 0u : 18u);
     p.refill = refill;
     return p;
 }

@@ -941,6 +941,9 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
             U4 cell = rc;
             float tb0 = 0.0f, tb1 = 0.0f;
             const bool any_node = __ballot(have) != 0ull;
+#ifdef MCRT_SECTION_PROFILE
+            PROF_ADD(PF_SCAN_STEPS, 1); PROF_ADD(PF_SCAN_LANES, __popcll(__ballot(have))); PROF_ADD(PF_IDLE_DONE, 64 - walking);
+#endif
             // the requested record is waited for HERE, on every path: left pending where no lane looks at a node, it made every later write to
             // one of its registers - the pop loop, the next request - wait for all loads in flight, the leaf records included
             asm volatile("" ::"v"(ra.x), "v"(rb.x), "v"(rc.x));
@@ -978,6 +981,10 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
             U4 a, b, c;
             a.x = a.y = a.z = a.w = 0u; b = a; c = a;
             if (dealing) {
+#ifdef MCRT_SECTION_PROFILE
+                PROF_ADD(PF_DEAL_STEPS, 1); PROF_ADD(PF_DEAL_LANES, total < 64u ? total : 64u);
+                PROF_ADD(PF_POST_HEAVY_LANES, __popcll(__ballot(descend)));
+#endif
                 // the markers of this deal carry a fresh tag: what earlier deals left in the slots reads as "none" (no zeroing pass)
                 epoch += 64u;
                 if (epoch == 0u) { L.slot[threadIdx.x] = 0u; wave_sync(); epoch = 64u; }     // the tag wrapped (2^26 deals): start over
