@@ -11,6 +11,7 @@ for A in scan brute octree; do
   timeout -k 10 400 python bench.py --accel $A --steps 2 --no-cpu-baseline --no-secondary > gpurun_out/${TAG}_bench_config2_$A.json 2> gpurun_out/${TAG}_bench_config2_$A.err || exit 1
 done
 MCRT_BENCH_REHEARSE=1 timeout -k 10 400 python bench.py --gpus 2 --steps 2 --no-cpu-baseline --no-secondary --workload cornell_512_64 > gpurun_out/${TAG}_bench_rehearse_gpus2.json 2> gpurun_out/${TAG}_bench_rehearse_gpus2.err || exit 1
+MCRT_BENCH_REHEARSE=1 timeout -k 10 400 python bench.py --gpus 2 --steps 2 --no-cpu-baseline --no-secondary --workload config4_1024_16 > gpurun_out/${TAG}_bench_rehearse_gpus2_config4.json 2> gpurun_out/${TAG}_bench_rehearse_gpus2_config4.err || exit 1
 for f in gpurun_out/${TAG}_bench_*.json; do python - "$f" <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
