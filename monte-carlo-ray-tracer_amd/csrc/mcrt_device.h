@@ -685,26 +685,52 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
             // the three crossings in order (a three-element sorting network; the axis bit travels with its distance)
             float k0 = c[0], k1 = c[1], k2 = c[2];
             uint32_t b0 = 1u, b1 = 2u, b2 = 4u;
-            if (k1 < k0) { const float t = k0; k0 = k1; k1 = t; const uint32_t u = b0; b0 = b1; b1 = u; }
-            if (k2 < k1) { const float t = k1; k1 = k2; k2 = t; const uint32_t u = b1; b1 = b2; b2 = u; }
-            if (k1 < k0) { const float t = k0; k0 = k1; k1 = t; const uint32_t u = b0; b0 = b1; b1 = u; }
+            // (compare-and-select, no branches: the compiler had turned two of the three swaps into exec-mask regions)
+#define MCRT_SORT2(KA, KB, BA, BB)                                                               \
+            {                                                                                    \
+                const bool sw = (KB) < (KA);                                                     \
+                const float lo = sw ? (KB) : (KA), hi = sw ? (KA) : (KB);                        \
+                const uint32_t blo = sw ? (BB) : (BA), bhi = sw ? (BA) : (BB);                   \
+                (KA) = lo; (KB) = hi; (BA) = blo; (BB) = bhi;                                    \
+            }
+            MCRT_SORT2(k0, k1, b0, b1)
+            MCRT_SORT2(k1, k2, b1, b2)
+            MCRT_SORT2(k0, k1, b0, b1)
+#undef MCRT_SORT2
             const uint32_t r1 = r0 ^ b0, r2 = r1 ^ b1, r3 = r2 ^ b2;
             // far to near; an octant whose entry lies behind the best hit so far (or that is not entered at all: +inf) is left out
-            const bool fast = st.room(sp, 4);
-#define MCRT_PUSH_OCTANT(R, T)                                                                   \
-            {                                                                                    \
-                const uint32_t oct = (R) ^ flip;                                                 \
-                if ((mask >> oct) & 1u) {                                                        \
+            if (st.room(sp, 4)) {
+                // Room for all four in the LDS part of the stack (the rule, deeper stacks are rare): every candidate is WRITTEN at the
+                // current top, and the top moves up only for a valid one - an invalid candidate is overwritten by the next write or stays
+                // above the top, where nobody looks.  Four unconditional writes and four adds instead of four nested exec-mask regions.
+#define MCRT_PUSH_OCTANT(R, T, OK)                                                               \
+                {                                                                                \
+                    const uint32_t oct = (R) ^ flip;                                             \
                     const uint32_t child = base + __popc(mask & ((1u << oct) - 1u));             \
-                    if (fast) st.put_fast(sp, (T), child); else st.put(sp, (T), child);          \
-                    ++sp;                                                                        \
-                }                                                                                \
-            }
-            if (k2 <= best_t) MCRT_PUSH_OCTANT(r3, fmaxf(tb0, k2))
-            if (k1 <= best_t) MCRT_PUSH_OCTANT(r2, fmaxf(tb0, k1))
-            if (k0 <= best_t) MCRT_PUSH_OCTANT(r1, fmaxf(tb0, k0))
-            MCRT_PUSH_OCTANT(r0, tb0)
+                    st.put_fast(sp, (T), child);                                                 \
+                    sp += ((OK) && ((mask >> oct) & 1u)) ? 1 : 0;                                \
+                }
+                MCRT_PUSH_OCTANT(r3, fmaxf(tb0, k2), k2 <= best_t)
+                MCRT_PUSH_OCTANT(r2, fmaxf(tb0, k1), k1 <= best_t)
+                MCRT_PUSH_OCTANT(r1, fmaxf(tb0, k0), k0 <= best_t)
+                MCRT_PUSH_OCTANT(r0, tb0, true)
 #undef MCRT_PUSH_OCTANT
+            } else {
+#define MCRT_PUSH_OCTANT(R, T)                                                                   \
+                {                                                                                \
+                    const uint32_t oct = (R) ^ flip;                                             \
+                    if ((mask >> oct) & 1u) {                                                    \
+                        const uint32_t child = base + __popc(mask & ((1u << oct) - 1u));         \
+                        st.put(sp, (T), child);                                                  \
+                        ++sp;                                                                    \
+                    }                                                                            \
+                }
+                if (k2 <= best_t) MCRT_PUSH_OCTANT(r3, fmaxf(tb0, k2))
+                if (k1 <= best_t) MCRT_PUSH_OCTANT(r2, fmaxf(tb0, k1))
+                if (k0 <= best_t) MCRT_PUSH_OCTANT(r1, fmaxf(tb0, k0))
+                MCRT_PUSH_OCTANT(r0, tb0)
+#undef MCRT_PUSH_OCTANT
+            }
         }
     }
 
