@@ -153,8 +153,6 @@ template <> struct WalkStackFor<GlbPtr> {
 };
 // LDS words the kernels that trace paths need after the SMALL image (octree walk over an HBM-resident image): the stack columns, then the
 // deal's per-thread hit keys (u64), hit objects and owner markers
-constexpr uint32_t kWalkStackWords = LDS_STACK_ENTRIES * 2 * LDS_STACK_BLOCK;
-constexpr uint32_t kWalkLdsWords = kWalkStackWords + 3 * LDS_STACK_BLOCK;
 template <class W> __device__ __forceinline__ typename W::Deal walk_deal_area(uint32_t* walk_lds)
 {
     typename W::Deal L;

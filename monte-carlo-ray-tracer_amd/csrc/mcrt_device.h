@@ -1424,6 +1424,36 @@ template <int kAccel, class PS, class PB, bool kCount> struct Caster {
         return cast_octree<PS, PB, kCount>(sm, big, v, o, d, cn);
     }
 };
+// LDS words of a walk over an HBM-resident image, after the SMALL image: the stack columns, then the deal's per-thread hit keys (u64)
+// and owner markers
+constexpr uint32_t kWalkStackWords = LDS_STACK_ENTRIES * 2 * LDS_STACK_BLOCK;
+constexpr uint32_t kWalkLdsWords = kWalkStackWords + 3 * LDS_STACK_BLOCK;
+// Nearest hit of a ray batch (mcrt_intersect, mcrt_render_unlit) through an octree walked from HBM: the same dealt walk the render kernel
+// runs, to the end of every ray.  All 64 lanes of the wavefront are here (the loops of those kernels are wave-uniform; a lane past the
+// end of the batch has live == false and helps with the dealt records).
+template <bool kCount> struct Caster<MCRT_ACCEL_OCTREE, LdsPtr, GlbPtr, kCount> {
+    static MCRT_DEV Hit run(LdsPtr sm, GlbPtr big, const SceneView& v, V3 o, V3 d, Counters& cn, bool live)
+    {
+        typedef OctreeWalk<LdsPtr, GlbPtr, kCount> Walk;
+        LdsRw base = (LdsRw)sm + ((v.small_words + 3u) & ~3u);
+        LdsStack st;
+        st.col = base + threadIdx.x;
+        typename Walk::Deal L;
+        L.key = (__attribute__((address_space(3))) unsigned long long*)(base + kWalkStackWords);
+        L.slot = base + kWalkStackWords + 2 * LDS_STACK_BLOCK;
+        L.slot[threadIdx.x] = 0u;          // the walk below starts its marker tags from scratch: nothing of an earlier batch may look like one
+        wave_sync();
+        Walk w;
+        w.idle();
+        if (live) w.begin_dealt(sm, big, v, st, L, o, d, cn);
+        w.run_dealt(sm, big, v, st, L, o, d, cn, 0u);
+        Hit h; h.prim = MISS; h.obj = MISS; h.elem = 0; h.t = kFltMax;
+        if (live) { w.collect_dealt(sm, v, L); h = w.best; }
+        wave_sync();                       // the keys are rewritten by the next batch
+        return h;
+    }
+};
+
 template <bool kCount> struct Caster<MCRT_ACCEL_FLAT, CstPtr, LdsPtr, kCount> {
     static MCRT_DEV Hit run(CstPtr sm, LdsPtr big, const SceneView& v, V3 o, V3 d, Counters& cn, bool live)
     {

@@ -752,6 +752,61 @@ def test_big_random_scenes_walked_from_hbm(pkg, oracle, scene_of, seed, monkeypa
     monkeypatch.delenv("MCRT_WAVEFRONT")
 
 
+def test_dealt_walk_on_adversarial_rays(pkg, oracle, scene_of):
+    """mcrt_intersect on an octree that lives in HBM runs the render kernel's walk (leaf records dealt over the wavefront, hits merged
+    by LDS atomics on (t, primitive id), next node requested ahead): a 12 000-triangle soup in the Cornell box, rays of every class
+    the fixtures hold - either side of the padding of the split planes with one tiny direction component, far origins, zero / NaN /
+    infinite components, random rays from inside and outside - against the oracle's brute force, bit for bit, in batch sizes that
+    leave partial wavefronts."""
+    import gen_golden as gg
+    from mcrt_amd import scenes
+
+    flat = scenes.config4(scene_of("cornell"), n=12_000, seed=7)
+    sc = oracle.scene(flat)
+    rng = np.random.default_rng(2024)
+    o1, d1 = gg.pad_margin_rays(flat, rng, total=24000, levels=4)
+    o2, d2 = gg.far_origin_rays(flat, rng, n=1500)
+    n = 12000
+    o3 = rng.uniform(-4.6, 4.6, (n, 3)).astype(np.float32)
+    d3 = rng.normal(size=(n, 3)).astype(np.float32)
+    d3 /= np.linalg.norm(d3, axis=1, keepdims=True)
+    o4 = (rng.normal(size=(n // 2, 3)) * 30.0).astype(np.float32)
+    d4 = (rng.uniform(-4.0, 4.0, (n // 2, 3)) - o4).astype(np.float32)
+    d4 /= np.linalg.norm(d4, axis=1, keepdims=True)
+    k = 256
+    o5 = rng.uniform(-4.0, 4.0, (8 * k, 3)).astype(np.float32)
+    d5 = rng.normal(size=(8 * k, 3)).astype(np.float32)
+    d5 /= np.linalg.norm(d5, axis=1, keepdims=True)
+    d5[0 * k:1 * k] = 0.0
+    d5[1 * k:2 * k, 0] = 0.0; d5[1 * k:2 * k, 1] = 0.0; d5[1 * k:2 * k, 2] = np.sign(d5[1 * k:2 * k, 2])
+    d5[2 * k:3 * k, 1] = np.float32(1e-38)
+    d5[2 * k:3 * k] /= np.linalg.norm(d5[2 * k:3 * k], axis=1, keepdims=True)
+    d5[3 * k:4 * k, 0] = np.nan
+    d5[4 * k:5 * k, 1] = np.inf
+    o5[5 * k:6 * k, 2] = np.nan
+    o5[6 * k:7 * k] *= np.float32(1e30)
+    o5[7 * k:8 * k, 0] = -np.inf
+    o = np.ascontiguousarray(np.concatenate([o1, o2, o3, o4, o5]), np.float32)
+    d = np.ascontiguousarray(np.concatenate([d1, d2, d3, d4, d5]), np.float32)
+    o, d = o[:len(o) - 37], d[:len(d) - 37]                     # not a multiple of 64
+    want = oracle.intersect(sc, o, d)
+    assert 0.3 < (want[0] >= 0).mean() < 0.99
+    b = pkg.Backend(0)
+    try:
+        for device_build in (False, True):
+            b.upload_scene(flat, device_build=device_build)
+            assert not b.octree_info().lds_resident
+            for mode in (pkg.ACCEL_OCTREE, pkg.ACCEL_AUTO):
+                b.set_accel(mode)
+                for lo, hi in ((0, len(o)), (5, 70), (100, 101)):
+                    obj, elem, t = b.intersect(o[lo:hi], d[lo:hi])
+                    hit = want[0][lo:hi] >= 0
+                    bad = np.flatnonzero((obj != want[0][lo:hi]) | (hit & ((elem != want[1][lo:hi]) | (t.view(np.uint32) != want[2][lo:hi].view(np.uint32)))))
+                    assert len(bad) == 0, (device_build, mode, lo, hi, len(bad), bad[:5], o[lo:hi][bad[:2]], d[lo:hi][bad[:2]], obj[bad[:2]], want[0][lo:hi][bad[:2]])
+    finally:
+        b.close()
+
+
 @pytest.mark.parametrize("scale,shift", [(1.0e4, 0.0), (1.0e-3, 0.0), (1.0, 1.0e4), (1.0, -3.0e5), (37.0, 911.0)])
 def test_octree_on_scaled_and_shifted_scenes(backend, pkg, oracle, scene_of, scale, shift):
     """The 2000-triangle scene blown up, shrunk and moved far from the origin (where an ulp of a coordinate is no longer small against

@@ -34,13 +34,19 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--levels", type=int, default=3)
     ap.add_argument("--accel", default="", help="max_leaf,max_depth,pad_rel of the tree (default: the library's)")
+    ap.add_argument("--soup", type=int, default=0, help="instead of the fixture scenes: the Cornell box with a soup of this many triangles (an octree that lives in HBM, so "
+                    "that mcrt_intersect runs the dealt walk of the render kernel); the checker is the CPU replay of the octree, itself checked against the brute force on the first 20000 rays")
     a = ap.parse_args()
     orc = po.Oracle()
     golden = os.path.join(ROOT, "tests", "golden")
     bad_total = 0
     backend = pkg.Backend(0) if a.gpu else None
-    for name in a.scene or ["config4_2k", "cornell", "config2"]:
-        flat = pkg.FlatScene.load(os.path.join(golden, f"scene_{name}.npz"))
+    for name in ([f"soup{a.soup}"] if a.soup else (a.scene or ["config4_2k", "cornell", "config2"])):
+        if a.soup:
+            from mcrt_amd import scenes
+            flat = scenes.config4(pkg.FlatScene.load(os.path.join(golden, "scene_cornell.npz")), n=a.soup, seed=a.seed)
+        else:
+            flat = pkg.FlatScene.load(os.path.join(golden, f"scene_{name}.npz"))
         sc = orc.scene(flat)
         rng = np.random.default_rng([a.seed, len(name)])
         accel = pkg.AccelParams(*[float(x) if i == 2 else int(x) for i, x in enumerate(a.accel.split(","))]) if a.accel else None
@@ -48,9 +54,13 @@ def main():
         fo, fd = gg.far_origin_rays(flat, rng, n=max(a.rays // 20, 10))
         o, d = np.ascontiguousarray(np.concatenate([o, fo])), np.ascontiguousarray(np.concatenate([d, fd]))
         t0 = time.time()
-        want = orc.intersect(sc, o, d)
         info, box, words, refs = pkg.build_scene_image(flat, accel)
         got = orc.intersect_octree(sc, info, box, words, refs, o, d)
+        if a.soup:
+            head = orc.intersect(sc, o[:20000], d[:20000])
+            want = tuple(np.concatenate([h, g[20000:]]) for h, g in zip(head, got))
+        else:
+            want = orc.intersect(sc, o, d)
         bad = ~((got[0] == want[0]) & (got[1] == want[1]) & (got[2].view(np.uint32) == want[2].view(np.uint32)))
         line = f"{name}: {len(o)} rays, hit fraction {float((want[0] >= 0).mean()):.3f}, cpu replay mismatches {int(bad.sum())}"
         if bad.any():

@@ -11,4 +11,8 @@ run --rays 1000000 --seed 13 --levels 4 --scene config4_2k --accel 1,12,0
 run --rays 1000000 --seed 14 --levels 3 --scene config4_2k --accel 2,6,1e-6
 run --rays 2000000 --seed 15 --levels 3 --scene cornell --scene config2 --scene config3 --scene hexagon
 run --rays 2000000 --seed 16 --levels 5 --scene cornell --scene config2 --scene three_lights --scene cornell_sphere_light
+# octrees that live in HBM: mcrt_intersect runs the dealt walk of the render kernel
+run --rays 1000000 --seed 21 --levels 4 --soup 12000
+run --rays 1000000 --seed 22 --levels 5 --soup 60000
+run --rays 1000000 --seed 23 --levels 3 --soup 30000 --accel 4,10,0
 tail -3 $OUT
