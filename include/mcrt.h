@@ -158,7 +158,9 @@ int mcrt_set_stream(mcrt_ctx* ctx, void* hip_stream);
  * source/accelerationstructures/octree.h:77-92 is rebuilt here as a flat,
  * per-primitive structure of node and leaf records).  `accel` may be NULL.
  * Limits (MCRT_ERR_LIMIT): at most 512 objects, and their table has to fit the
- * LDS budget; fewer than 2^24 octree nodes.  accel->max_depth above
+ * LDS budget; at most 8388607 primitives (spheres + triangles: the length of a
+ * node's list is a 23-bit field of its record); fewer than 2^24 octree nodes.
+ * accel->max_depth above
  * MCRT_MAX_TREE_DEPTH (12) is clamped to it, not refused: deeper levels only
  * split cells that are already smaller than 1/4096 of the scene. */
 #define MCRT_MAX_TREE_DEPTH 12
