@@ -139,6 +139,12 @@ struct PendStack {
     }
 };
 
+__device__ __forceinline__ U4 u4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { U4 r; r.x = a; r.y = b; r.z = c; r.w = d; return r; }
+__device__ __forceinline__ uint32_t dlo(double v) { return (uint32_t)(uint64_t)__double_as_longlong(v); }
+__device__ __forceinline__ uint32_t dhi(double v) { return (uint32_t)((uint64_t)__double_as_longlong(v) >> 32); }
+__device__ __forceinline__ double dmake(uint32_t lo, uint32_t hi) { return __longlong_as_double((long long)((uint64_t)lo | ((uint64_t)hi << 32))); }
+__device__ __forceinline__ U4 dd4(double a, double b) { return u4(dlo(a), dhi(a), dlo(b), dhi(b)); }
+
 struct RenderCounters { uint32_t samples, trace_calls, splits; };
 
 template <class PB> struct WalkStackFor {
@@ -699,11 +705,6 @@ struct WfArgs {
     uint32_t first;          // shade: no answered queries yet - every slot starts from scratch
 };
 
-__device__ __forceinline__ U4 u4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { U4 r; r.x = a; r.y = b; r.z = c; r.w = d; return r; }
-__device__ __forceinline__ uint32_t dlo(double v) { return (uint32_t)(uint64_t)__double_as_longlong(v); }
-__device__ __forceinline__ uint32_t dhi(double v) { return (uint32_t)((uint64_t)__double_as_longlong(v) >> 32); }
-__device__ __forceinline__ double dmake(uint32_t lo, uint32_t hi) { return __longlong_as_double((long long)((uint64_t)lo | ((uint64_t)hi << 32))); }
-__device__ __forceinline__ U4 dd4(double a, double b) { return u4(dlo(a), dhi(a), dlo(b), dhi(b)); }
 
 template <bool kMulti>
 __device__ __forceinline__ void wf_store(const LaneState<kMulti>& s, uint32_t slice, U4* st, uint32_t slots, uint32_t slot)
