@@ -803,6 +803,11 @@ def test_dealt_walk_on_adversarial_rays(pkg, oracle, scene_of):
                     hit = want[0][lo:hi] >= 0
                     bad = np.flatnonzero((obj != want[0][lo:hi]) | (hit & ((elem != want[1][lo:hi]) | (t.view(np.uint32) != want[2][lo:hi].view(np.uint32)))))
                     assert len(bad) == 0, (device_build, mode, lo, hi, len(bad), bad[:5], o[lo:hi][bad[:2]], d[lo:hi][bad[:2]], obj[bad[:2]], want[0][lo:hi][bad[:2]])
+        # Scene::TraceUnlit (scene.cpp:82-92) through the same walk: a 50 x 37 image (1850 rays: a partial last wavefront) against the oracle
+        cam = oracle.camera(50, 37, 90.0, POS, TGT)
+        b.set_accel(pkg.ACCEL_AUTO)
+        b.set_camera(cam)
+        assert np.array_equal(b.render_unlit(), oracle.render_unlit(sc, cam))
     finally:
         b.close()
 
