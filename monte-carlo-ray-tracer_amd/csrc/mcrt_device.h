@@ -64,6 +64,21 @@ typedef uint32_t U4 __attribute__((ext_vector_type(4)));
 MCRT_DEV U4 ld4(LdsPtr p, uint32_t i) { return *(const __attribute__((address_space(3))) U4*)(p + i); }
 MCRT_DEV U4 ld4(GlbPtr p, uint32_t i) { return *(const U4*)(p + i); }
 MCRT_DEV U4 ld4(CstPtr p, uint32_t i) { return *(const __attribute__((address_space(4))) U4*)(p + i); }
+// The three 16-byte words of one 48-byte record (octree node or leaf record).  From global memory: ONE 64-bit address - index x 3,
+// shifted by the add that forms the address - and the second and third word through the load's immediate offset; with the word index
+// worked out in 32 bits (rec, rec + 4, rec + 8) the compiler built three addresses, each with its own 64-bit add, after a
+// quarter-rate integer multiply.
+static_assert(NODE_STRIDE == 12 && LEAF_STRIDE == 12, "ld_rec48 reads 48-byte records");
+MCRT_DEV void ld_rec48(GlbPtr base, uint32_t idx, U4& a, U4& b, U4& c)
+{
+    const U4* p = (const U4*)base + (size_t)(idx * 3u);
+    a = p[0]; b = p[1]; c = p[2];
+}
+MCRT_DEV void ld_rec48(LdsPtr base, uint32_t idx, U4& a, U4& b, U4& c)
+{
+    const uint32_t r = idx * 12u;
+    a = ld4(base, r); b = ld4(base, r + 4); c = ld4(base, r + 8);
+}
 
 struct TriRec { V3 v0, e1, e2; };
 template <class P> MCRT_DEV TriRec load_tri(P big, uint32_t rec)
@@ -952,8 +967,7 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
             }                                                                                     \
             /* every lane loads (a lane without a node: the root's record, a cache hit): three loads that are issued on every path can be */ \
             /* counted, and the wait for the leaf records becomes vmcnt(3) instead of vmcnt(0) - which would wait for these loads too */ \
-            const uint32_t rec = (have ? w_in : 0u) * NODE_STRIDE;                                \
-            ra = ld4(nodes, rec); rb = ld4(nodes, rec + 4); rc = ld4(nodes, rec + 8);             \
+            ld_rec48(nodes, have ? w_in : 0u, ra, rb, rc);                                        \
             asm volatile("" ::: "memory");                                                        \
         }
         MCRT_REQUEST_NODE()
@@ -1029,8 +1043,7 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
                 if (eager) pgate = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)gate_lo);
                 {
                     // (lanes without a pair load record 0: loads issued on every path can be counted by the compiler's wait insertion)
-                    const uint32_t w = (mine ? r : 0u) * LEAF_STRIDE;
-                    a = ld4(leaves, w); b = ld4(leaves, w + 4); c = ld4(leaves, w + 8);
+                    ld_rec48(leaves, mine ? r : 0u, a, b, c);
                     asm volatile("" ::: "memory");             // the records travel while the octants are worked out
                 }
                 // the owners move on: what is dealt now is as good as tested
@@ -1056,7 +1069,7 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
                     float t = 0.0f;
                     const uint32_t prim = c.y & ~REF_LAST;
                     const uint32_t obj = c.z & ~LEAF_SPHERE;
-                    const uint32_t orec = v.off_obj + obj * OBJ_STRIDE;
+                    const uint32_t orec = v.off_obj + __umul24(obj, OBJ_STRIDE);       // obj < MAX_OBJECTS: the full-rate multiply
                     if (c.z & LEAF_SPHERE) {
                         if (kCount) cn.spheres++;
                         h = sphere_hit(sm, orec, po, pd, t);
