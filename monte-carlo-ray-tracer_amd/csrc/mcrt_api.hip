@@ -284,9 +284,19 @@ template <bool kMulti> struct LaneState {
     // cannot move a draw).  What waits for the shadow query is one comparison and one multiply-add.
     // kMulti: scenes with more than one light test the further lights one query at a time from a saved copy of the
     // generator (the state that path needs is compiled out of the one-light kernels).
+    // `lazy.item(*this)` is called before the first access to the item's fields (sum, pixel, s_begin, s_count, k, dropped): a caller that
+    // keeps the state parked in memory fetches them only for the lanes whose sample ends (trace_lane_parked); NoLazy for everybody else.
+    struct NoLazy { __device__ __forceinline__ void item(LaneState&) const {} };
     template <class PS, class PB, class Work>
     __device__ __forceinline__ void post(const Hit& hit, PS sm, PB big, const SceneView& v, const D3& background, const PendStack& pend, bool keep_nonfinite,
                                          Work& work, const ExplicitStart* ex, RenderCounters& rc, bool count)
+    {
+        NoLazy lazy;
+        post(hit, sm, big, v, background, pend, keep_nonfinite, work, ex, rc, count, lazy);
+    }
+    template <class PS, class PB, class Work, class Lazy>
+    __device__ __forceinline__ void post(const Hit& hit, PS sm, PB big, const SceneView& v, const D3& background, const PendStack& pend, bool keep_nonfinite,
+                                         Work& work, const ExplicitStart* ex, RenderCounters& rc, bool count, Lazy& lazy)
     {
         bool branch_done = false;      // this TraceRay chain returned; continue with a parked branch or finish the sample
         bool lights_done = false;      // every light of the current diffuse hit is accounted for
@@ -430,6 +440,7 @@ template <bool kMulti> struct LaneState {
                 state = ST_TRACE;
             } else {
                 // PixelBuffer::Accumulate, source/core/pixelbuffer.cpp:39-46 (non-finite samples dropped)
+                lazy.item(*this);
                 const bool fin = isfinite(L.x) && isfinite(L.y) && isfinite(L.z);
                 if (fin || keep_nonfinite) sum = sum + L;
                 else dropped += 1;
@@ -666,6 +677,10 @@ struct RenderWork {
     }
 };
 
+template <class PS, class PB, bool kCount, bool kMulti>
+__device__ __forceinline__ void trace_lane_parked(PS sm, PB big, const SceneView& v, const CameraDev& cam, uint64_t seed, uint32_t max_depth, const PendStack& pend,
+                                                  Counters& cn, RenderCounters& rc, RenderWork& work, const LanePolicy policy, uint32_t* walk_lds, U4* park, uint32_t slots);
+
 template <bool kBigLds, int kAccel, bool kCount, bool kMulti, bool kCold = false>
 __global__ __launch_bounds__(kBlock, (kAccel == MCRT_ACCEL_OCTREE && !kBigLds) ? MCRT_WALK_BLOCKS : 4) void k_render(const RenderArgs a)
 {
@@ -795,20 +810,105 @@ __device__ __forceinline__ void wf_load(LaneState<kMulti>& s, uint32_t& slice, c
 // registers) live across the walk; at the 128 registers of four wavefronts per SIMD the compiler then spills the walk's own hot
 // variables (the stack pointer, the list counter) to scratch, and every reload waits for ALL outstanding loads - the node and leaf
 // records included, which serialises the very round trips the walk tries to overlap.  Here the state is PARKED in HBM between two
-// shadings (wf_store / wf_load, the chunk-major layout of the wavefront pipeline, slot = launched lane): a lane carries its ray and
+// shadings (ParkIO: 16-byte chunks, chunk-major as in the wavefront pipeline, one column per launched lane): a lane carries its ray and
 // its state word through the walk and nothing else, and loads the rest only when its query is answered - post, pre, store.  Same
-// LaneState code, same numbers.  512 bytes of coalesced traffic per query against the ~3 KB of records a walk fetches.
+// LaneState code, same numbers.  About 256 bytes of coalesced traffic per query against the ~3 KB of records a walk fetches.
+// The parked state in three groups, so that a shading pass moves what it needs (16-byte chunks, chunk-major, one column per launched lane):
+//   A  chunks 0-3    generator, importance, radiance: every pass, both ways
+//   I  chunks 4-6    the item (sum, pixel, sample range, counters, slice): read and written back by the lanes whose sample ends (LaneState::post
+//                    asks for it through `lazy.item`), i.e. once per sample instead of once per query
+//   D  chunks 7-13   the diffuse-hit context (+ 14-16 with several lights): written by a lane that leaves with a shadow ray, read by a lane that
+//                    comes back from one - every other pass of a diffuse path, one way each
+// The ray, the state word, the remaining depth and the parked-branch count never leave the registers (state | depth << 3 | npend << 12).
+// 8 chunks per lane and pass on average instead of 32.
+constexpr uint32_t kParkChunksMulti = 17;     // 14 with one light
+template <bool kMulti> struct ParkIO {
+    U4* p;          // chunk 0 of this lane
+    size_t n;       // launched lanes
+    __device__ __forceinline__ void load_a(LaneState<kMulti>& s) const
+    {
+        const U4 c0 = p[0 * n], c1 = p[1 * n], c2 = p[2 * n], c3 = p[3 * n];
+        s.g.s0 = (uint64_t)c0.x | ((uint64_t)c0.y << 32); s.g.s1 = (uint64_t)c0.z | ((uint64_t)c0.w << 32);
+        s.imp = dmk(dmake(c1.x, c1.y), dmake(c1.z, c1.w), dmake(c2.x, c2.y));
+        s.L = dmk(dmake(c2.z, c2.w), dmake(c3.x, c3.y), dmake(c3.z, c3.w));
+    }
+    __device__ __forceinline__ void store_a(const LaneState<kMulti>& s) const
+    {
+        p[0 * n] = u4((uint32_t)s.g.s0, (uint32_t)(s.g.s0 >> 32), (uint32_t)s.g.s1, (uint32_t)(s.g.s1 >> 32));
+        p[1 * n] = dd4(s.imp.x, s.imp.y);
+        p[2 * n] = dd4(s.imp.z, s.L.x);
+        p[3 * n] = dd4(s.L.y, s.L.z);
+    }
+    __device__ __forceinline__ void load_i(LaneState<kMulti>& s, uint32_t& slice) const
+    {
+        const U4 c4 = p[4 * n], c5 = p[5 * n], c6 = p[6 * n];
+        s.sum = dmk(dmake(c4.x, c4.y), dmake(c4.z, c4.w), dmake(c5.x, c5.y));
+        s.pixel = c5.z; s.s_begin = c5.w;
+        s.s_count = c6.x; s.k = c6.y; s.dropped = c6.z; slice = c6.w;
+    }
+    __device__ __forceinline__ void store_i(const LaneState<kMulti>& s, uint32_t slice) const
+    {
+        p[4 * n] = dd4(s.sum.x, s.sum.y);
+        p[5 * n] = u4(dlo(s.sum.z), dhi(s.sum.z), s.pixel, s.s_begin);
+        p[6 * n] = u4(s.s_count, s.k, s.dropped, slice);
+    }
+    __device__ __forceinline__ void load_d(LaneState<kMulti>& s) const
+    {
+        const U4 c7 = p[7 * n], c8 = p[8 * n], c9 = p[9 * n], c10 = p[10 * n], c11 = p[11 * n], c12 = p[12 * n], c13 = p[13 * n];
+        s.hp = mk(__uint_as_float(c7.x), __uint_as_float(c7.y), __uint_as_float(c7.z));
+        s.light_i = c7.w & 0x7FFFFFFFu; s.survive = (c7.w >> 31) != 0u;
+        s.bd = mk(__uint_as_float(c8.x), __uint_as_float(c8.y), __uint_as_float(c8.z)); s.horec = c8.w;
+        s.impc = dmk(dmake(c9.x, c9.y), dmake(c9.z, c9.w), dmake(c10.x, c10.y));
+        s.direct = dmk(dmake(c10.z, c10.w), dmake(c11.x, c11.y), dmake(c11.z, c11.w));
+        s.p_survive = dmake(c12.x, c12.y); s.g_bounce = dmake(c12.z, c12.w);
+        s.w_light = dmake(c13.x, c13.y);
+        if constexpr (kMulti) {
+            const U4 a = p[14 * n], b = p[15 * n], e = p[16 * n];
+            s.hn = mk(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+            s.hd = mk(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+            s.g_l.s0 = (uint64_t)e.x | ((uint64_t)e.y << 32); s.g_l.s1 = (uint64_t)e.z | ((uint64_t)e.w << 32);
+        }
+    }
+    __device__ __forceinline__ void store_d(const LaneState<kMulti>& s) const
+    {
+        p[7 * n] = u4(__float_as_uint(s.hp.x), __float_as_uint(s.hp.y), __float_as_uint(s.hp.z), s.light_i | (s.survive ? 0x80000000u : 0u));
+        p[8 * n] = u4(__float_as_uint(s.bd.x), __float_as_uint(s.bd.y), __float_as_uint(s.bd.z), s.horec);
+        p[9 * n] = dd4(s.impc.x, s.impc.y);
+        p[10 * n] = dd4(s.impc.z, s.direct.x);
+        p[11 * n] = dd4(s.direct.y, s.direct.z);
+        p[12 * n] = dd4(s.p_survive, s.g_bounce);
+        p[13 * n] = u4(dlo(s.w_light), dhi(s.w_light), 0u, 0u);
+        if constexpr (kMulti) {
+            p[14 * n] = u4(__float_as_uint(s.hn.x), __float_as_uint(s.hn.y), __float_as_uint(s.hn.z), 0u);
+            p[15 * n] = u4(__float_as_uint(s.hd.x), __float_as_uint(s.hd.y), __float_as_uint(s.hd.z), 0u);
+            p[16 * n] = u4((uint32_t)s.g_l.s0, (uint32_t)(s.g_l.s0 >> 32), (uint32_t)s.g_l.s1, (uint32_t)(s.g_l.s1 >> 32));
+        }
+    }
+};
+// LaneState::post's hook: the item's fields arrive when the lane's sample ends
+template <bool kMulti> struct ParkLazy {
+    const ParkIO<kMulti>& io;
+    RenderWork& work;
+    bool touched;
+    __device__ __forceinline__ void item(LaneState<kMulti>& s)
+    {
+        if (!touched) { io.load_i(s, work.slice); touched = true; }
+    }
+};
+__device__ __forceinline__ uint32_t park_pack(uint32_t state, uint32_t depth, uint32_t npend) { return state | (depth << 3) | (npend << 12); }
+
 template <class PS, class PB, bool kCount, bool kMulti>
 __device__ __forceinline__ void trace_lane_parked(PS sm, PB big, const SceneView& v, const CameraDev& cam, uint64_t seed, uint32_t max_depth, const PendStack& pend,
                                                   Counters& cn, RenderCounters& rc, RenderWork& work, const LanePolicy policy, uint32_t* walk_lds, U4* park, uint32_t slots)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t state = ST_FETCH;
+    const ParkIO<kMulti> io = { park + slot, (size_t)slots };
+    uint32_t sd = park_pack(ST_FETCH, 0u, 0u);             // state | depth << 3 | npend << 12
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
     {
         LaneState<kMulti> ln;
         ln.init();
-        wf_store(ln, 0u, park, slots, slot);
+        io.store_a(ln); io.store_i(ln, 0u);
     }
     ExplicitStart exs;
     const ExplicitStart* ex = nullptr;
@@ -831,6 +931,7 @@ __device__ __forceinline__ void trace_lane_parked(PS sm, PB big, const SceneView
         if (pt_shade) PROF_ADD(PF_POST_T, pt_top - pt_shade);
         PROF_ADD(PF_ITER, 1);
 #endif
+        const uint32_t state = sd & 7u;
         const uint64_t busy = __ballot(state != ST_DONE);
         if (busy == 0ull) break;
         bool fetch_ok = true;
@@ -839,15 +940,19 @@ __device__ __forceinline__ void trace_lane_parked(PS sm, PB big, const SceneView
             fetch_ok = (uint32_t)__popcll(want) >= kFetchMin || want == busy;
         }
         if ((state == ST_FETCH && fetch_ok) || state == ST_NEW) {
+            // (the start of the launch, and lanes that waited to fetch together: the diffuse-hit context is dead in both states)
             LaneState<kMulti> ln;
-            wf_load(ln, work.slice, park, slots, slot);
+            ln.init();
+            ln.state = state; ln.depth = (sd >> 3) & 0x1FFu; ln.npend = sd >> 12;
+            io.load_a(ln); io.load_i(ln, work.slice);
             ln.pre(fetch_ok, work, cam, seed, max_depth, exs, ex, rc, kCount);
-            wf_store(ln, work.slice, park, slots, slot);
-            state = ln.state; ro = ln.ro; rd = ln.rd;
+            io.store_a(ln); io.store_i(ln, work.slice);
+            sd = park_pack(ln.state, ln.depth, ln.npend); ro = ln.ro; rd = ln.rd;
         }
-        bool live = state != ST_FETCH && state != ST_DONE;
+        const uint32_t st = sd & 7u;
+        bool live = st != ST_FETCH && st != ST_DONE;
         if (kMinTrace > 0u && live) {
-            const bool is_s = state == ST_SHADOW;
+            const bool is_s = st == ST_SHADOW;
             const uint32_t n_s = (uint32_t)__popcll(__ballot(is_s)), n_t = (uint32_t)__popcll(__ballot(!is_s));
             live = is_s || n_t >= kMinTrace || n_s == 0u;
         }
@@ -869,12 +974,18 @@ __device__ __forceinline__ void trace_lane_parked(PS sm, PB big, const SceneView
         walk.collect_dealt(sm, v, deal);
         {
             LaneState<kMulti> ln;
-            wf_load(ln, work.slice, park, slots, slot);
+            ln.init();
+            ln.state = st; ln.depth = (sd >> 3) & 0x1FFu; ln.npend = sd >> 12; ln.ro = ro; ln.rd = rd;
+            io.load_a(ln);
+            if (st == ST_SHADOW) io.load_d(ln);
+            ParkLazy<kMulti> lazy = { io, work, false };
             const D3 background = ldd3(sm, v.off_bg);
-            ln.post(walk.best, sm, big, v, background, pend, false, work, ex, rc, kCount);
+            ln.post(walk.best, sm, big, v, background, pend, false, work, ex, rc, kCount, lazy);
             if (ln.state == ST_NEW || (ln.state == ST_FETCH && kFetchMin <= 1u)) ln.pre(true, work, cam, seed, max_depth, exs, ex, rc, kCount);
-            wf_store(ln, work.slice, park, slots, slot);
-            state = ln.state; ro = ln.ro; rd = ln.rd;
+            io.store_a(ln);
+            if (ln.state == ST_SHADOW) io.store_d(ln);
+            if (lazy.touched) io.store_i(ln, work.slice);
+            sd = park_pack(ln.state, ln.depth, ln.npend); ro = ln.ro; rd = ln.rd;
         }
     }
 }
@@ -1422,7 +1533,7 @@ int ensure_pend(mcrt_ctx* c, uint32_t max_depth)
 // The parked estimator state (trace_lane_parked): 16-byte chunks, chunk-major, one column per launched lane.
 int ensure_park(mcrt_ctx* c)
 {
-    const size_t bytes = (size_t)grid_for(c) * kBlock * kWfChunksMulti * 16u;
+    const size_t bytes = (size_t)grid_for(c) * kBlock * kParkChunksMulti * 16u;
     if (bytes > c->park_bytes) {
         if (c->d_park) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(c->d_park)); c->d_park = nullptr; c->park_bytes = 0; }
         HIP_TRY(c, hipMalloc(&c->d_park, bytes));
