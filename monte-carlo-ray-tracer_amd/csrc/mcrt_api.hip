@@ -457,11 +457,7 @@ template <bool kMulti> struct LaneState {
 // pixel - one at a time (Work::next) and takes back the sum of the item's finite samples in sample
 // order plus the number dropped (Work::done; keep_nonfinite: the raw value, used by the parity path
 // with s_count == 1).  Every loop iteration is exactly one nearest-hit query: LaneState::pre, the query, LaneState::post.
-// kCold (flat kernel, when 24 more LDS columns fit in the block's 40 KB): the fields of the diffuse-hit context that nothing reads
-// during the query (impc, direct, hp, bd, p_survive, g_bounce, w_light: 24 dwords per lane) wait in LDS columns, one dword column per
-// thread, while the query runs - 20 registers fewer to spill at the 128-VGPR cap (profiles/r03_park_cold_experiment.txt).
-constexpr uint32_t kColdWords = 24;
-template <class PS, class PB, int kAccel, bool kCount, bool kMulti, class Work, bool kCold = false>
+template <class PS, class PB, int kAccel, bool kCount, bool kMulti, class Work>
 __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, const CameraDev& cam, uint64_t seed, uint32_t max_depth,
                                            const PendStack& pend, bool keep_nonfinite, Counters& cn, RenderCounters& rc, Work& work,
                                            const LanePolicy policy, uint32_t* walk_lds)
@@ -537,27 +533,7 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
                 if constexpr (kDeal) walk.collect_dealt(sm, v, deal);
                 hit = walk.best;
             } else {
-                LdsRw cold = nullptr;
-                if constexpr (kCold) {
-                    cold = (LdsRw)big + (((v.ntri * TRI_STRIDE + 3u) & ~3u) + (kBlock / 64) * FLAT_AREA_WORDS) + threadIdx.x;
-                    const double dd[9] = { ln.impc.x, ln.impc.y, ln.impc.z, ln.direct.x, ln.direct.y, ln.direct.z, ln.p_survive, ln.g_bounce, ln.w_light };
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) { cold[(2 * q) * kBlock] = dlo(dd[q]); cold[(2 * q + 1) * kBlock] = dhi(dd[q]); }
-                    const float ff[6] = { ln.hp.x, ln.hp.y, ln.hp.z, ln.bd.x, ln.bd.y, ln.bd.z };
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) cold[(18 + q) * kBlock] = __float_as_uint(ff[q]);
-                    asm volatile("" ::: "memory");
-                }
                 hit = cast<kAccel, PS, PB, kCount>(sm, big, v, ln.ro, ln.rd, cn, live);
-                if constexpr (kCold) {
-                    asm volatile("" ::: "memory");
-                    double dd[9];
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) dd[q] = dmake(cold[(2 * q) * kBlock], cold[(2 * q + 1) * kBlock]);
-                    ln.impc = dmk(dd[0], dd[1], dd[2]); ln.direct = dmk(dd[3], dd[4], dd[5]); ln.p_survive = dd[6]; ln.g_bounce = dd[7]; ln.w_light = dd[8];
-                    ln.hp = mk(__uint_as_float(cold[18 * kBlock]), __uint_as_float(cold[19 * kBlock]), __uint_as_float(cold[20 * kBlock]));
-                    ln.bd = mk(__uint_as_float(cold[21 * kBlock]), __uint_as_float(cold[22 * kBlock]), __uint_as_float(cold[23 * kBlock]));
-                }
 #ifdef MCRT_SECTION_PROFILE
                 PROF_ADD(PF_CAST_T, PROF_NOW() - pt_cast); PROF_ADD(PF_CAST_LANES, __popcll(__ballot(live)));
                 PROF_ADD(PF_IDLE_FETCH, __popcll(__ballot(ln.state == ST_FETCH))); PROF_ADD(PF_IDLE_DONE, __popcll(__ballot(ln.state == ST_DONE)));
@@ -681,7 +657,7 @@ template <class PS, class PB, bool kCount, bool kMulti>
 __device__ __forceinline__ void trace_lane_parked(PS sm, PB big, const SceneView& v, const CameraDev& cam, uint64_t seed, uint32_t max_depth, const PendStack& pend,
                                                   Counters& cn, RenderCounters& rc, RenderWork& work, const LanePolicy policy, uint32_t* walk_lds, U4* park, uint32_t slots);
 
-template <bool kBigLds, int kAccel, bool kCount, bool kMulti, bool kCold = false>
+template <bool kBigLds, int kAccel, bool kCount, bool kMulti>
 __global__ __launch_bounds__(kBlock, (kAccel == MCRT_ACCEL_OCTREE && !kBigLds) ? MCRT_WALK_BLOCKS : 4) void k_render(const RenderArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -706,7 +682,7 @@ __global__ __launch_bounds__(kBlock, (kAccel == MCRT_ACCEL_OCTREE && !kBigLds) ?
         trace_lane_parked<typename Mem::PS, typename Mem::PB, kCount, kMulti>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, cn, rc, work, a.policy, walk_lds, (U4*)a.park,
                                                                                 gridDim.x * blockDim.x);
     else
-        trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount, kMulti, RenderWork, kCold>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, false, cn, rc, work, a.policy, walk_lds);
+        trace_lane<typename Mem::PS, typename Mem::PB, kAccel, kCount, kMulti>(sm, big, a.view, a.cam, a.seed, a.max_depth, pend, false, cn, rc, work, a.policy, walk_lds);
 #ifdef MCRT_SECTION_PROFILE
     PROF_ADD(PF_WAVES, 1); PROF_ADD(PF_TOTAL_T, PROF_NOW() - pt_kernel);
     if ((threadIdx.x & 63u) < (uint32_t)PF_COUNT) atomicAdd(&g_prof[threadIdx.x & 63u], prof_slots()[threadIdx.x & 63u]);
@@ -1488,8 +1464,6 @@ size_t lds_for(const mcrt_ctx* c)
 
 // the flat scan keeps the triangle records and its per-wavefront work areas in LDS and packs (object, element) into 32 bits
 size_t flat_lds_bytes(const mcrt_ctx* c) { return (size_t)c->view.ntri * TRI_STRIDE * 4u + 16u + (kBlock / 64) * FLAT_AREA_WORDS * 4u; }
-// the render kernel's cold columns (trace_lane, kCold) go behind the flat areas when the block stays within 40 KB (4 blocks per CU)
-bool flat_cold_ok(const mcrt_ctx* c) { return c->accel == MCRT_ACCEL_FLAT && flat_lds_bytes(c) + kColdWords * kBlock * 4u <= 40u * 1024u; }
 bool flat_ok(const mcrt_ctx* c)
 {
     return c->view.has_pairs && c->view.ntri < (1u << FLAT_ELEM_BITS) && c->view.nobj < 4095u && flat_lds_bytes(c) <= 40u * 1024u;   // 4 blocks per CU
@@ -1552,13 +1526,7 @@ template <class K> int set_lds_limit(mcrt_ctx* c, K kernel, size_t bytes)
 template <bool kBigLds, int kAccel, bool kCount> int launch_render_t(mcrt_ctx* c, const RenderArgs& a)
 {
     auto kern = (kCount || c->view.nlights > 1) ? k_render<kBigLds, kAccel, kCount, true> : k_render<kBigLds, kAccel, kCount, kCount>;
-    size_t lds = lds_for(c);
-    if constexpr (kAccel == MCRT_ACCEL_FLAT && kBigLds && !kCount) {
-        if (flat_cold_ok(c)) {
-            kern = c->view.nlights > 1 ? k_render<kBigLds, kAccel, kCount, true, true> : k_render<kBigLds, kAccel, kCount, kCount, true>;
-            lds += kColdWords * kBlock * 4u;
-        }
-    }
+    const size_t lds = lds_for(c);
     int rc = set_lds_limit(c, kern, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(grid_for(c)), dim3(kBlock), lds, c->stream, a);
