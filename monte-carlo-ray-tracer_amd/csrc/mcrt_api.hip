@@ -498,7 +498,16 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
         const unsigned long long pt_pre = PROF_NOW();
         PROF_ADD(PF_ITER, 1); PROF_ADD(PF_PRE_LANES, __popcll(__ballot(ln.state == ST_NEW || (ln.state == ST_FETCH && fetch_ok))));
 #endif
-        ln.pre(fetch_ok, work, cam, seed, max_depth, exs, ex, rc, kCount);
+        // Samples start in batches too: a lane between two samples (or about to take an item) would only join the trace lanes that wait for
+        // their batch, so the start - seed hash, camera ray: ~200 instructions for the wavefront, whoever needs them - runs in the iterations
+        // in which that batch is served, for all the lanes that got there meanwhile, instead of in nearly every iteration for a few.
+        bool start_ok = true;
+        if (kMinTrace > 0u) {
+            const bool starts = ln.state == ST_NEW || (ln.state == ST_FETCH && fetch_ok);
+            const uint32_t n_s = (uint32_t)__popcll(__ballot(ln.state == ST_SHADOW)), n_t = (uint32_t)__popcll(__ballot(ln.state == ST_TRACE || starts));
+            start_ok = n_t >= kMinTrace || n_s == 0u;
+        }
+        if (start_ok) ln.pre(fetch_ok, work, cam, seed, max_depth, exs, ex, rc, kCount);
 #ifdef MCRT_SECTION_PROFILE
         const unsigned long long pt_cast = PROF_NOW();
         PROF_ADD(PF_PRE_T, pt_cast - pt_pre);
@@ -513,7 +522,7 @@ __device__ __forceinline__ void trace_lane(PS sm, PB big, const SceneView& v, co
             // for that about every other iteration, with most of its lanes in it, instead of every iteration for a minority.
             // Break-even by the instruction counts (cast ~2050, shading ~1200 per wavefront): wait when fewer than ~3/8 of the lanes are ready;
             // measured optimum of the threshold over configs 1, 2, 3 and 5: 36 (sweep 0 / 12 / 24 / 36 / 64, profiles/r02_sweep_min_trace.txt).
-            bool live = ln.state != ST_FETCH && ln.state != ST_DONE;          // a lane waiting for an item, or finished, has no ray
+            bool live = ln.state == ST_TRACE || ln.state == ST_SHADOW;        // a lane waiting for an item or for its start, or finished, has no ray
             if (kMinTrace > 0u && live) {
                 const bool is_s = ln.state == ST_SHADOW;
                 const uint32_t n_s = (uint32_t)__popcll(__ballot(is_s)), n_t = (uint32_t)__popcll(__ballot(!is_s));
