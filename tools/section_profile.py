@@ -23,7 +23,7 @@ be.upload_scene(flat)
 be.set_camera(pkg.host_camera(W, H, 90.0, (0, 0, 5), (0, 0, 0)))
 lib = be.lib
 out = (C.c_uint64 * 32)()
-be.clear(); be.render(0, spp, 100, 0x5EED0001)          # warm-up
+be.clear(); be.render(0, spp, 100, 0x5EED0001); be.last_render_ms()      # warm-up (waited for: its wavefronts must not add to the counters read below)
 assert lib.mcrt_debug_section_profile(out) == 0
 be.clear(); be.render(0, spp, 100, 0x5EED0001)
 ms = be.last_render_ms()

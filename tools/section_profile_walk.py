@@ -21,7 +21,7 @@ be = pkg.Backend(0)
 be.upload_scene(flat)
 be.set_camera(pkg.host_camera(W, H, 90.0, (0, 0, 5), (0, 0, 0)))
 out = (C.c_uint64 * 32)()
-be.clear(); be.render(0, spp, 100, 0x5EED0001)
+be.clear(); be.render(0, spp, 100, 0x5EED0001); be.last_render_ms()
 assert be.lib.mcrt_debug_section_profile(out) == 0
 be.clear(); be.render(0, spp, 100, 0x5EED0001)
 ms = be.last_render_ms()
