@@ -795,10 +795,10 @@ __device__ __forceinline__ void wf_load(LaneState<kMulti>& s, uint32_t& slice, c
 // registers) live across the walk; at the 128 registers of four wavefronts per SIMD the compiler then spills the walk's own hot
 // variables (the stack pointer, the list counter) to scratch, and every reload waits for ALL outstanding loads - the node and leaf
 // records included, which serialises the very round trips the walk tries to overlap.  Here the state is PARKED in HBM between two
-// shadings (ParkIO: 16-byte chunks, chunk-major as in the wavefront pipeline, one column per launched lane): a lane carries its ray and
+// shadings (ParkIO: 16-byte chunks in three groups, lane-major inside a group): a lane carries its ray and
 // its state word through the walk and nothing else, and loads the rest only when its query is answered - post, pre, store.  Same
 // LaneState code, same numbers.  About 256 bytes of coalesced traffic per query against the ~3 KB of records a walk fetches.
-// The parked state in three groups, so that a shading pass moves what it needs (16-byte chunks, chunk-major, one column per launched lane):
+// The parked state in three groups, so that a shading pass moves what it needs (16-byte chunks; group by group, lane-major inside a group):
 //   A  chunks 0-3    generator, importance, radiance: every pass, both ways
 //   I  chunks 4-6    the item (sum, pixel, sample range, counters, slice): read and written back by the lanes whose sample ends (LaneState::post
 //                    asks for it through `lazy.item`), i.e. once per sample instead of once per query
@@ -806,40 +806,51 @@ __device__ __forceinline__ void wf_load(LaneState<kMulti>& s, uint32_t& slice, c
 //                    comes back from one - every other pass of a diffuse path, one way each
 // The ray, the state word, the remaining depth and the parked-branch count never leave the registers (state | depth << 3 | npend << 12).
 // 8 chunks per lane and pass on average instead of 32.
-constexpr uint32_t kParkChunksMulti = 17;     // 14 with one light
+constexpr uint32_t kParkChunksMulti = 20;     // 17 used with several lights, 14 with one (lane-major groups are padded to whole sectors)
 template <bool kMulti> struct ParkIO {
-    U4* p;          // chunk 0 of this lane
+    U4* base;       // the parked state of the launch
     size_t n;       // launched lanes
+    size_t slot;    // this lane
+    // lane-major inside a group: the chunks of one lane's group fill whole 64-byte sectors of their own (A: 64 B, I: 48 of 64 B, D: 112 of
+    // 128 B, 160 of 192 B with several lights), so a pass in which some of the lanes take part moves those lanes' sectors and no others
+    // (chunk-major columns, four lanes to a sector, moved 1.5x the bytes: 46.2 -> 45.4 ms)
+    static constexpr size_t kD = kMulti ? 12 : 8;
+    __device__ __forceinline__ U4& at(uint32_t k) const
+    {
+        if (k < 4u) return base[slot * 4u + k];
+        if (k < 7u) return base[n * 4u + slot * 4u + (k - 4u)];
+        return base[n * 8u + slot * kD + (k - 7u)];
+    }
     __device__ __forceinline__ void load_a(LaneState<kMulti>& s) const
     {
-        const U4 c0 = p[0 * n], c1 = p[1 * n], c2 = p[2 * n], c3 = p[3 * n];
+        const U4 c0 = at(0), c1 = at(1), c2 = at(2), c3 = at(3);
         s.g.s0 = (uint64_t)c0.x | ((uint64_t)c0.y << 32); s.g.s1 = (uint64_t)c0.z | ((uint64_t)c0.w << 32);
         s.imp = dmk(dmake(c1.x, c1.y), dmake(c1.z, c1.w), dmake(c2.x, c2.y));
         s.L = dmk(dmake(c2.z, c2.w), dmake(c3.x, c3.y), dmake(c3.z, c3.w));
     }
     __device__ __forceinline__ void store_a(const LaneState<kMulti>& s) const
     {
-        p[0 * n] = u4((uint32_t)s.g.s0, (uint32_t)(s.g.s0 >> 32), (uint32_t)s.g.s1, (uint32_t)(s.g.s1 >> 32));
-        p[1 * n] = dd4(s.imp.x, s.imp.y);
-        p[2 * n] = dd4(s.imp.z, s.L.x);
-        p[3 * n] = dd4(s.L.y, s.L.z);
+        at(0) = u4((uint32_t)s.g.s0, (uint32_t)(s.g.s0 >> 32), (uint32_t)s.g.s1, (uint32_t)(s.g.s1 >> 32));
+        at(1) = dd4(s.imp.x, s.imp.y);
+        at(2) = dd4(s.imp.z, s.L.x);
+        at(3) = dd4(s.L.y, s.L.z);
     }
     __device__ __forceinline__ void load_i(LaneState<kMulti>& s, uint32_t& slice) const
     {
-        const U4 c4 = p[4 * n], c5 = p[5 * n], c6 = p[6 * n];
+        const U4 c4 = at(4), c5 = at(5), c6 = at(6);
         s.sum = dmk(dmake(c4.x, c4.y), dmake(c4.z, c4.w), dmake(c5.x, c5.y));
         s.pixel = c5.z; s.s_begin = c5.w;
         s.s_count = c6.x; s.k = c6.y; s.dropped = c6.z; slice = c6.w;
     }
     __device__ __forceinline__ void store_i(const LaneState<kMulti>& s, uint32_t slice) const
     {
-        p[4 * n] = dd4(s.sum.x, s.sum.y);
-        p[5 * n] = u4(dlo(s.sum.z), dhi(s.sum.z), s.pixel, s.s_begin);
-        p[6 * n] = u4(s.s_count, s.k, s.dropped, slice);
+        at(4) = dd4(s.sum.x, s.sum.y);
+        at(5) = u4(dlo(s.sum.z), dhi(s.sum.z), s.pixel, s.s_begin);
+        at(6) = u4(s.s_count, s.k, s.dropped, slice);
     }
     __device__ __forceinline__ void load_d(LaneState<kMulti>& s) const
     {
-        const U4 c7 = p[7 * n], c8 = p[8 * n], c9 = p[9 * n], c10 = p[10 * n], c11 = p[11 * n], c12 = p[12 * n], c13 = p[13 * n];
+        const U4 c7 = at(7), c8 = at(8), c9 = at(9), c10 = at(10), c11 = at(11), c12 = at(12), c13 = at(13);
         s.hp = mk(__uint_as_float(c7.x), __uint_as_float(c7.y), __uint_as_float(c7.z));
         s.light_i = c7.w & 0x7FFFFFFFu; s.survive = (c7.w >> 31) != 0u;
         s.bd = mk(__uint_as_float(c8.x), __uint_as_float(c8.y), __uint_as_float(c8.z)); s.horec = c8.w;
@@ -848,7 +859,7 @@ template <bool kMulti> struct ParkIO {
         s.p_survive = dmake(c12.x, c12.y); s.g_bounce = dmake(c12.z, c12.w);
         s.w_light = dmake(c13.x, c13.y);
         if constexpr (kMulti) {
-            const U4 a = p[14 * n], b = p[15 * n], e = p[16 * n];
+            const U4 a = at(14), b = at(15), e = at(16);
             s.hn = mk(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
             s.hd = mk(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
             s.g_l.s0 = (uint64_t)e.x | ((uint64_t)e.y << 32); s.g_l.s1 = (uint64_t)e.z | ((uint64_t)e.w << 32);
@@ -856,17 +867,17 @@ template <bool kMulti> struct ParkIO {
     }
     __device__ __forceinline__ void store_d(const LaneState<kMulti>& s) const
     {
-        p[7 * n] = u4(__float_as_uint(s.hp.x), __float_as_uint(s.hp.y), __float_as_uint(s.hp.z), s.light_i | (s.survive ? 0x80000000u : 0u));
-        p[8 * n] = u4(__float_as_uint(s.bd.x), __float_as_uint(s.bd.y), __float_as_uint(s.bd.z), s.horec);
-        p[9 * n] = dd4(s.impc.x, s.impc.y);
-        p[10 * n] = dd4(s.impc.z, s.direct.x);
-        p[11 * n] = dd4(s.direct.y, s.direct.z);
-        p[12 * n] = dd4(s.p_survive, s.g_bounce);
-        p[13 * n] = u4(dlo(s.w_light), dhi(s.w_light), 0u, 0u);
+        at(7) = u4(__float_as_uint(s.hp.x), __float_as_uint(s.hp.y), __float_as_uint(s.hp.z), s.light_i | (s.survive ? 0x80000000u : 0u));
+        at(8) = u4(__float_as_uint(s.bd.x), __float_as_uint(s.bd.y), __float_as_uint(s.bd.z), s.horec);
+        at(9) = dd4(s.impc.x, s.impc.y);
+        at(10) = dd4(s.impc.z, s.direct.x);
+        at(11) = dd4(s.direct.y, s.direct.z);
+        at(12) = dd4(s.p_survive, s.g_bounce);
+        at(13) = u4(dlo(s.w_light), dhi(s.w_light), 0u, 0u);
         if constexpr (kMulti) {
-            p[14 * n] = u4(__float_as_uint(s.hn.x), __float_as_uint(s.hn.y), __float_as_uint(s.hn.z), 0u);
-            p[15 * n] = u4(__float_as_uint(s.hd.x), __float_as_uint(s.hd.y), __float_as_uint(s.hd.z), 0u);
-            p[16 * n] = u4((uint32_t)s.g_l.s0, (uint32_t)(s.g_l.s0 >> 32), (uint32_t)s.g_l.s1, (uint32_t)(s.g_l.s1 >> 32));
+            at(14) = u4(__float_as_uint(s.hn.x), __float_as_uint(s.hn.y), __float_as_uint(s.hn.z), 0u);
+            at(15) = u4(__float_as_uint(s.hd.x), __float_as_uint(s.hd.y), __float_as_uint(s.hd.z), 0u);
+            at(16) = u4((uint32_t)s.g_l.s0, (uint32_t)(s.g_l.s0 >> 32), (uint32_t)s.g_l.s1, (uint32_t)(s.g_l.s1 >> 32));
         }
     }
 };
@@ -887,7 +898,7 @@ __device__ __forceinline__ void trace_lane_parked(PS sm, PB big, const SceneView
                                                   Counters& cn, RenderCounters& rc, RenderWork& work, const LanePolicy policy, uint32_t* walk_lds, U4* park, uint32_t slots)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const ParkIO<kMulti> io = { park + slot, (size_t)slots };
+    const ParkIO<kMulti> io = { park, (size_t)slots, (size_t)slot };
     uint32_t sd = park_pack(ST_FETCH, 0u, 0u);             // state | depth << 3 | npend << 12
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
     {
@@ -1513,7 +1524,7 @@ int ensure_pend(mcrt_ctx* c, uint32_t max_depth)
     return MCRT_OK;
 }
 
-// The parked estimator state (trace_lane_parked): 16-byte chunks, chunk-major, one column per launched lane.
+// The parked estimator state (trace_lane_parked, ParkIO): 20 chunks of 16 bytes per launched lane.
 int ensure_park(mcrt_ctx* c)
 {
     const size_t bytes = (size_t)grid_for(c) * kBlock * kParkChunksMulti * 16u;

@@ -68,15 +68,27 @@ MCRT_DEV U4 ld4(CstPtr p, uint32_t i) { return *(const __attribute__((address_sp
 // shifted by the add that forms the address - and the second and third word through the load's immediate offset; with the word index
 // worked out in 32 bits (rec, rec + 4, rec + 8) the compiler built three addresses, each with its own 64-bit add, after a
 // quarter-rate integer multiply.
-static_assert(NODE_STRIDE == 12 && LEAF_STRIDE == 12, "ld_rec48 reads 48-byte records");
+static_assert((NODE_STRIDE == 12 || NODE_STRIDE == 16) && LEAF_STRIDE == 12, "ld_rec48 / ld_node read 48-byte records");
 MCRT_DEV void ld_rec48(GlbPtr base, uint32_t idx, U4& a, U4& b, U4& c)
 {
     const U4* p = (const U4*)base + (size_t)(idx * 3u);
     a = p[0]; b = p[1]; c = p[2];
 }
+// a node record: 48 bytes at a stride of NODE_STRIDE words
+MCRT_DEV void ld_node(GlbPtr base, uint32_t idx, U4& a, U4& b, U4& c)
+{
+    if (NODE_STRIDE == 12) { ld_rec48(base, idx, a, b, c); return; }
+    const U4* p = (const U4*)base + (size_t)idx * (NODE_STRIDE / 4);
+    a = p[0]; b = p[1]; c = p[2];
+}
 MCRT_DEV void ld_rec48(LdsPtr base, uint32_t idx, U4& a, U4& b, U4& c)
 {
     const uint32_t r = idx * 12u;
+    a = ld4(base, r); b = ld4(base, r + 4); c = ld4(base, r + 8);
+}
+MCRT_DEV void ld_node(LdsPtr base, uint32_t idx, U4& a, U4& b, U4& c)
+{
+    const uint32_t r = idx * NODE_STRIDE;
     a = ld4(base, r); b = ld4(base, r + 4); c = ld4(base, r + 8);
 }
 
@@ -967,7 +979,7 @@ template <class PS, class PB, bool kCount> struct OctreeWalk {
             }                                                                                     \
             /* every lane loads (a lane without a node: the root's record, a cache hit): three loads that are issued on every path can be */ \
             /* counted, and the wait for the leaf records becomes vmcnt(3) instead of vmcnt(0) - which would wait for these loads too */ \
-            ld_rec48(nodes, have ? w_in : 0u, ra, rb, rc);                                        \
+            ld_node(nodes, have ? w_in : 0u, ra, rb, rc);                                          \
             asm volatile("" ::: "memory");                                                        \
         }
         MCRT_REQUEST_NODE()

@@ -68,7 +68,11 @@ enum : uint32_t {
     NODE_CELL = 8,       // min corner of the node's cell, 3 floats (the builder's own values)
     NODE_SCALE = 11,     // 2^-depth as a float (sign and exponent bits, the mantissa of a power of two is zero) with the LENGTH of
                          // the node's own list in the 23 mantissa bits: a lane that begins a list knows how many records follow
+#ifdef MCRT_NODE_STRIDE
+    NODE_STRIDE = MCRT_NODE_STRIDE
+#else
     NODE_STRIDE = 12
+#endif
 };
 constexpr uint32_t NODE_SCALE_MASK = 0xFF800000u, NODE_COUNT_MASK = 0x007FFFFFu;
 constexpr uint32_t MAX_PRIMITIVES = NODE_COUNT_MASK;      // a list holds a primitive once at most
