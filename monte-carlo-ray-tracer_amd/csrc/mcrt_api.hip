@@ -804,17 +804,18 @@ __device__ __forceinline__ void wf_load(LaneState<kMulti>& s, uint32_t& slice, c
 //                    asks for it through `lazy.item`), i.e. once per sample instead of once per query
 //   D  chunks 7-13   the diffuse-hit context (+ 14-16 with several lights): written by a lane that leaves with a shadow ray, read by a lane that
 //                    comes back from one - every other pass of a diffuse path, one way each
-// The ray, the state word, the remaining depth and the parked-branch count never leave the registers (state | depth << 3 | npend << 12).
+// The ray, the state word, the remaining depth, the parked-branch count and the roulette outcome never leave the registers
+// (state | depth << 3 | npend << 12 | survive << 30).
 // 8 chunks per lane and pass on average instead of 32.
 constexpr uint32_t kParkChunksMulti = 20;     // 17 used with several lights, 14 with one (lane-major groups are padded to whole sectors)
 template <bool kMulti> struct ParkIO {
     U4* base;       // the parked state of the launch
     size_t n;       // launched lanes
     size_t slot;    // this lane
-    // lane-major inside a group: the chunks of one lane's group fill whole 64-byte sectors of their own (A: 64 B, I: 48 of 64 B, D: 112 of
-    // 128 B, 160 of 192 B with several lights), so a pass in which some of the lanes take part moves those lanes' sectors and no others
+    // lane-major inside a group: the chunks of one lane's group fill whole 64-byte sectors of their own (A: 64 B, I: 48 of 64 B, D: 64 B,
+    // 160 of 192 B with several lights), so a pass in which some of the lanes take part moves those lanes' sectors and no others
     // (chunk-major columns, four lanes to a sector, moved 1.5x the bytes: 46.2 -> 45.4 ms)
-    static constexpr size_t kD = kMulti ? 12 : 8;
+    static constexpr size_t kD = kMulti ? 12 : 4;
     __device__ __forceinline__ U4& at(uint32_t k) const
     {
         if (k < 4u) return base[slot * 4u + k];
@@ -850,6 +851,19 @@ template <bool kMulti> struct ParkIO {
     }
     __device__ __forceinline__ void load_d(LaneState<kMulti>& s) const
     {
+        if constexpr (!kMulti) {
+            // one light: 64 bytes, one sector - the light index and the direct sum are zero while the shadow ray of the only light is out,
+            // the roulette threshold is a function of the importance (group A, unchanged since the hit), `survive` travels in the state word
+            const U4 c7 = at(7), c8 = at(8), c9 = at(9), c10 = at(10);
+            s.hp = mk(__uint_as_float(c7.x), __uint_as_float(c7.y), __uint_as_float(c7.z));
+            s.bd = mk(__uint_as_float(c7.w), __uint_as_float(c8.x), __uint_as_float(c8.y));
+            s.g_bounce = dmake(c8.z, c8.w);
+            s.impc = dmk(dmake(c9.x, c9.y), dmake(c9.z, c9.w), dmake(c10.x, c10.y));
+            s.w_light = dmake(c10.z, c10.w);
+            s.light_i = 0u; s.direct = dmk(0.0, 0.0, 0.0);
+            s.p_survive = max_importance(s.imp);
+            return;
+        }
         const U4 c7 = at(7), c8 = at(8), c9 = at(9), c10 = at(10), c11 = at(11), c12 = at(12), c13 = at(13);
         s.hp = mk(__uint_as_float(c7.x), __uint_as_float(c7.y), __uint_as_float(c7.z));
         s.light_i = c7.w & 0x7FFFFFFFu; s.survive = (c7.w >> 31) != 0u;
@@ -867,6 +881,13 @@ template <bool kMulti> struct ParkIO {
     }
     __device__ __forceinline__ void store_d(const LaneState<kMulti>& s) const
     {
+        if constexpr (!kMulti) {
+            at(7) = u4(__float_as_uint(s.hp.x), __float_as_uint(s.hp.y), __float_as_uint(s.hp.z), __float_as_uint(s.bd.x));
+            at(8) = u4(__float_as_uint(s.bd.y), __float_as_uint(s.bd.z), dlo(s.g_bounce), dhi(s.g_bounce));
+            at(9) = dd4(s.impc.x, s.impc.y);
+            at(10) = dd4(s.impc.z, s.w_light);
+            return;
+        }
         at(7) = u4(__float_as_uint(s.hp.x), __float_as_uint(s.hp.y), __float_as_uint(s.hp.z), s.light_i | (s.survive ? 0x80000000u : 0u));
         at(8) = u4(__float_as_uint(s.bd.x), __float_as_uint(s.bd.y), __float_as_uint(s.bd.z), s.horec);
         at(9) = dd4(s.impc.x, s.impc.y);
@@ -891,7 +912,7 @@ template <bool kMulti> struct ParkLazy {
         if (!touched) { io.load_i(s, work.slice); touched = true; }
     }
 };
-__device__ __forceinline__ uint32_t park_pack(uint32_t state, uint32_t depth, uint32_t npend) { return state | (depth << 3) | (npend << 12); }
+__device__ __forceinline__ uint32_t park_pack(uint32_t state, uint32_t depth, uint32_t npend, bool survive) { return state | (depth << 3) | (npend << 12) | (survive ? 0x40000000u : 0u); }
 
 template <class PS, class PB, bool kCount, bool kMulti>
 __device__ __forceinline__ void trace_lane_parked(PS sm, PB big, const SceneView& v, const CameraDev& cam, uint64_t seed, uint32_t max_depth, const PendStack& pend,
@@ -899,7 +920,7 @@ __device__ __forceinline__ void trace_lane_parked(PS sm, PB big, const SceneView
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     const ParkIO<kMulti> io = { park, (size_t)slots, (size_t)slot };
-    uint32_t sd = park_pack(ST_FETCH, 0u, 0u);             // state | depth << 3 | npend << 12
+    uint32_t sd = park_pack(ST_FETCH, 0u, 0u, false);      // state | depth << 3 | npend << 12 | survive << 30
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
     {
         LaneState<kMulti> ln;
@@ -939,11 +960,11 @@ __device__ __forceinline__ void trace_lane_parked(PS sm, PB big, const SceneView
             // (the start of the launch, and lanes that waited to fetch together: the diffuse-hit context is dead in both states)
             LaneState<kMulti> ln;
             ln.init();
-            ln.state = state; ln.depth = (sd >> 3) & 0x1FFu; ln.npend = sd >> 12;
+            ln.state = state; ln.depth = (sd >> 3) & 0x1FFu; ln.npend = (sd >> 12) & 0x1FFu;
             io.load_a(ln); io.load_i(ln, work.slice);
             ln.pre(fetch_ok, work, cam, seed, max_depth, exs, ex, rc, kCount);
             io.store_a(ln); io.store_i(ln, work.slice);
-            sd = park_pack(ln.state, ln.depth, ln.npend); ro = ln.ro; rd = ln.rd;
+            sd = park_pack(ln.state, ln.depth, ln.npend, ln.survive); ro = ln.ro; rd = ln.rd;
         }
         const uint32_t st = sd & 7u;
         bool live = st != ST_FETCH && st != ST_DONE;
@@ -967,13 +988,13 @@ __device__ __forceinline__ void trace_lane_parked(PS sm, PB big, const SceneView
 #endif
         if (!live || !walk.done()) continue;          // no ray, or still in mid-traversal: nothing to shade yet
         walking = false;
-        walk.collect_dealt(sm, v, deal);
         {
             LaneState<kMulti> ln;
             ln.init();
-            ln.state = st; ln.depth = (sd >> 3) & 0x1FFu; ln.npend = sd >> 12; ln.ro = ro; ln.rd = rd;
+            ln.state = st; ln.depth = (sd >> 3) & 0x1FFu; ln.npend = (sd >> 12) & 0x1FFu; ln.survive = (sd >> 30) != 0u; ln.ro = ro; ln.rd = rd;
             io.load_a(ln);
             if (st == ST_SHADOW) io.load_d(ln);
+            walk.collect_dealt(sm, v, deal);          // (LDS reads: they run under the HBM round trip of the loads above)
             ParkLazy<kMulti> lazy = { io, work, false };
             const D3 background = ldd3(sm, v.off_bg);
             ln.post(walk.best, sm, big, v, background, pend, false, work, ex, rc, kCount, lazy);
@@ -981,7 +1002,7 @@ __device__ __forceinline__ void trace_lane_parked(PS sm, PB big, const SceneView
             io.store_a(ln);
             if (ln.state == ST_SHADOW) io.store_d(ln);
             if (lazy.touched) io.store_i(ln, work.slice);
-            sd = park_pack(ln.state, ln.depth, ln.npend); ro = ln.ro; rd = ln.rd;
+            sd = park_pack(ln.state, ln.depth, ln.npend, ln.survive); ro = ln.ro; rd = ln.rd;
         }
     }
 }
@@ -1744,7 +1765,7 @@ LanePolicy lane_policy(const mcrt_ctx* c)
     p.fetch_min = c->fetch_min_override >= 1 ? (uint32_t)c->fetch_min_override : (walk_hbm ? 1u : 64u);
     // measured (profiles/r01_refill_sweep.txt): refilling pays when the image is walked from HBM/L2 (long, exponentially distributed
     // walks); with an LDS-resident image the extra shading passes cost more than they save
-    const uint32_t refill = c->refill_override >= 0 ? (uint32_t)c->refill_override : (c->big_in_lds ? 0u : 18u);
+    const uint32_t refill = c->refill_override >= 0 ? (uint32_t)c->refill_override : (c->big_in_lds ? 0u : 30u);
     p.refill = refill;
     return p;
 }
