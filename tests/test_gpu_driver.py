@@ -752,6 +752,46 @@ def test_big_random_scenes_walked_from_hbm(pkg, oracle, scene_of, seed, monkeypa
     monkeypatch.delenv("MCRT_WAVEFRONT")
 
 
+def test_parked_walk_with_several_lights_and_glass(pkg, oracle, scene_of):
+    """The render kernel over an octree that lives in HBM keeps the estimator state parked between shadings and moves it in groups
+    (item, diffuse-hit context, the rest).  Here with everything that state has: three lights of three kinds (the further lights'
+    context and their own generator), a glass sphere (parked branches) and a mirror sphere in a 6 000-triangle soup - per-sample
+    radiance and a small render against the oracle, bit for bit, host- and device-built tree; then the same scene with one light
+    (the one-sector diffuse context of the one-light kernels)."""
+    from mcrt_amd import abi, scenes
+
+    one = scenes.config4(scene_of("cornell"), n=6_000, seed=11)
+    one = scenes.add_sphere(one, (1.6, -3.6, 1.2), 1.2, scenes.material(surface=abi.SURFACE_REFRACTIVE, ior=1.5))
+    one = scenes.add_sphere(one, (-2.0, -3.9, -1.0), 1.0, scenes.material(surface=abi.SURFACE_SPECULAR))
+    cam = oracle.camera(56, 40, 90.0, POS, TGT)
+    rng = np.random.default_rng(77)
+    px = rng.integers(0, 56 * 40, 700).astype(np.uint32)
+    sm = rng.integers(0, 4000, 700).astype(np.uint32)
+    b = pkg.Backend(0)
+    try:
+        for flat, lights in ((scenes.more_lights(one), 3), (one, 1)):
+            sc = oracle.scene(flat)
+            assert len(oracle.scene_lights(sc)) == lights
+            ref = oracle.trace_samples(sc, cam, px, sm, SEED, 100, portable_math=True, forward_sum=True)
+            img, _ = oracle.render(sc, cam, 0, 5, 100, SEED, threads=8, portable_math=True, forward_sum=True, lanes_per_pixel=pkg.lanes_per_pixel(56, 40, 5))
+            for device_build in (False, True):
+                b.upload_scene(flat, device_build=device_build)
+                assert not b.octree_info().lds_resident
+                b.set_camera(cam)
+                got = b.trace_samples(px, sm, SEED, 100)
+                same = (got.view(np.uint64) == ref.view(np.uint64)).all(axis=1) | (np.isnan(got).any(axis=1) & np.isnan(ref).any(axis=1))
+                assert same.all(), (lights, device_build)
+                b.clear(); b.render(0, 5, 100, SEED)
+                assert np.array_equal(b.read_accumulator(), img), (lights, device_build)
+                # a second pass on top, from sample 5 on: the parked state of the first launch must not leak into it
+                b.render(5, 3, 100, SEED)
+                more, _ = oracle.render(sc, cam, 5, 3, 100, SEED, threads=8, portable_math=True, forward_sum=True, lanes_per_pixel=pkg.lanes_per_pixel(56, 40, 3),
+                                        sums=img.copy())
+                assert np.array_equal(b.read_accumulator(), more), (lights, device_build)
+    finally:
+        b.close()
+
+
 def test_dealt_walk_on_adversarial_rays(pkg, oracle, scene_of):
     """mcrt_intersect on an octree that lives in HBM runs the render kernel's walk (leaf records dealt over the wavefront, hits merged
     by LDS atomics on (t, primitive id), next node requested ahead): a 12 000-triangle soup in the Cornell box, rays of every class
